@@ -1,0 +1,68 @@
+// Shared device/host helpers for libvita_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vita_hip.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define WAVE 64
+
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+  __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+  return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
+  return __builtin_bit_cast(float, ((uint32_t)b) << 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16_bits(lo) | ((uint32_t)f32_to_bf16_bits(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// physical -> logical index through a segment map (0 = identity); returns -1 when dropped
+__device__ __host__ __forceinline__ int64_t seg_map(int64_t i, int32_t seg_phys, int32_t seg_log) {
+  if (seg_phys == 0) return i;
+  const int64_t q = i / seg_phys, r = i % seg_phys;
+  return r < seg_log ? q * seg_log + r : -1;
+}
+
+void vita_set_error(const char* what, hipError_t e);
+#define VITA_CHECK_LAUNCH(name)                      \
+  do {                                               \
+    hipError_t e__ = hipGetLastError();              \
+    if (e__ != hipSuccess) {                         \
+      vita_set_error(name, e__);                     \
+      return VITA_ERR_LAUNCH;                        \
+    }                                                \
+  } while (0)
+#define VITA_REQUIRE(cond)                                   \
+  do {                                                       \
+    if (!(cond)) {                                           \
+      vita_set_error("invalid argument: " #cond, hipSuccess); \
+      return VITA_ERR_INVALID_ARG;                           \
+    }                                                        \
+  } while (0)

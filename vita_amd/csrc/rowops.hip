@@ -1,0 +1,558 @@
+// HBM-bound row kernels of the ViTa hot path (gfx950): LayerNorm fwd/bwd (one wave per row,
+// 64-lane shuffle reductions), rank-by-counting argsort + mask, row gather/scatter, im2col of
+// 3D+T patches, token assembly (+pos-embed, cls), casts, column sums, materialised-softmax rows,
+// weight-shadow packing and Adam.
+#include "common.h"
+
+static thread_local char g_err[256] = "";
+void vita_set_error(const char* what, hipError_t e) {
+  snprintf(g_err, sizeof(g_err), "%s%s%s", what, e != hipSuccess ? ": " : "", e != hipSuccess ? hipGetErrorString(e) : "");
+}
+extern "C" const char* vita_last_error(void) { return g_err; }
+extern "C" int vita_version(void) { return 100; }
+
+// ------------------------------------------------------------------------------------- LayerNorm
+#define LN_MAXV 8   // float4 per lane -> d <= 2048
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     void* __restrict__ y, int64_t ldy, int y_f32,
+                                                     float* __restrict__ mean, float* __restrict__ rstd,
+                                                     int64_t rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * ldx;
+  f32x4 v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < d) {
+      v[i] = *reinterpret_cast<const f32x4*>(xr + c);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { if (c + r >= d) v[i][r] = 0.f; s += v[i][r]; }
+    }
+  }
+  const float mu = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) if (c + r < d) { const float t = v[i][r] - mu; q += t * t; }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)d + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c >= ldy) continue;
+    float o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (c + r < d) ? (v[i][r] - mu) * rs * gamma[c + r] + beta[c + r] : 0.f;
+    if (y_f32) *reinterpret_cast<f32x4*>((float*)y + row * ldy + c) = f32x4{o[0], o[1], o[2], o[3]};
+    else *reinterpret_cast<u32x2*>((uint16_t*)y + row * ldy + c) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+  }
+}
+
+extern "C" int vita_layernorm_fwd(const float* x, int64_t ldx, const float* gamma, const float* beta, void* y,
+                                  int64_t ldy, int32_t y_dtype, float* mean, float* rstd, int64_t rows,
+                                  int64_t d, float eps, void* stream) {
+  VITA_REQUIRE(x && gamma && beta && y && mean && rstd);
+  VITA_REQUIRE(rows > 0 && d > 0 && d <= LN_MAXV * 256 && ldy <= LN_MAXV * 256);
+  VITA_REQUIRE(ldx % 4 == 0 && ldx >= ((d + 3) / 4) * 4 && ldy % 4 == 0 && ldy >= d);
+  VITA_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0);
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma,
+                     beta, y, ldy, y_dtype == VITA_DT_F32, mean, rstd, rows, (int)d, eps);
+  VITA_CHECK_LAUNCH("vita_layernorm_fwd");
+  return VITA_OK;
+}
+
+#define LN_BWD_MAXBLK 512
+extern "C" int64_t vita_layernorm_bwd_nblk(int64_t rows) {
+  int64_t n = (rows + 3) / 4;
+  return n < LN_BWD_MAXBLK ? n : LN_BWD_MAXBLK;
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, int64_t lddy, int dy_f32,
+                                                     const float* __restrict__ x, int64_t ldx,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ dx_in,
+                                                     float* __restrict__ dx_out, int64_t lddx, uint16_t* __restrict__ dxb,
+                                                     int64_t ld_dxb, float* __restrict__ partial, int64_t rows, int d) {
+  __shared__ float red[2][4][LN_MAXV * 256];   // 64 KB
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nblk = gridDim.x;
+  f32x4 g[LN_MAXV];
+  f32x4 ag[LN_MAXV], ab[LN_MAXV];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    ag[i] = ab[i] = g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) if (c + r < d) g[i][r] = gamma[c + r];
+  }
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)nblk * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[LN_MAXV], dyv[LN_MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      xh[i] = dyv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < d) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + row * ldx + c);
+        if (dy_f32) dyv[i] = *reinterpret_cast<const f32x4*>((const float*)dy + row * lddy + c);
+        else {
+          const u32x2 u = *reinterpret_cast<const u32x2*>((const uint16_t*)dy + row * lddy + c);
+          dyv[i] = f32x4{bf16_bits_to_f32((uint16_t)(u[0] & 0xffff)), bf16_bits_to_f32((uint16_t)(u[0] >> 16)),
+                         bf16_bits_to_f32((uint16_t)(u[1] & 0xffff)), bf16_bits_to_f32((uint16_t)(u[1] >> 16))};
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (c + r < d) {
+            xh[i][r] = (xv[r] - mu) * rs;
+            const float t = dyv[i][r] * g[i][r];
+            s1 += t; s2 += t * xh[i][r];
+            ag[i][r] += dyv[i][r] * xh[i][r];
+            ab[i][r] += dyv[i][r];
+          } else { dyv[i][r] = 0.f; }
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) / (float)d, c2 = wave_sum(s2) / (float)d;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c >= lddx) continue;
+      f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < d) {
+        if (dx_in) o = *reinterpret_cast<const f32x4*>(dx_in + row * lddx + c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (c + r < d) ? o[r] + rs * (dyv[i][r] * g[i][r] - c1 - xh[i][r] * c2) : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(dx_out + row * lddx + c) = o;
+      if (dxb && c < ld_dxb)
+        *reinterpret_cast<u32x2*>(dxb + row * ld_dxb + c) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+    }
+  }
+  // block reduce of dgamma/dbeta partials over the 4 waves
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { red[0][wave][c + r] = ag[i][r]; red[1][wave][c + r] = ab[i][r]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) {
+    partial[(int64_t)blockIdx.x * d + c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    partial[((int64_t)nblk + blockIdx.x) * d + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+  }
+}
+
+__global__ void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblk, int d, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= d) return;
+  float a = 0.f, b = 0.f;
+  for (int k = 0; k < nblk; ++k) { a += partial[(int64_t)k * d + c]; b += partial[((int64_t)nblk + k) * d + c]; }
+  dgamma[c] = a; dbeta[c] = b;
+}
+
+extern "C" int vita_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx,
+                                  const float* gamma, const float* mean, const float* rstd, const float* dx_in,
+                                  float* dx_out, int64_t lddx, void* dx_bf16, int64_t ld_dxb, float* dgamma,
+                                  float* dbeta, float* partial, int64_t rows, int64_t d, void* stream) {
+  VITA_REQUIRE(dy && x && gamma && mean && rstd && dx_out && dgamma && dbeta && partial);
+  VITA_REQUIRE(rows > 0 && d > 0 && d <= LN_MAXV * 256 && lddx <= LN_MAXV * 256);
+  VITA_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && lddx >= d && ldx >= ((d + 3) / 4) * 4 && lddy >= ((d + 3) / 4) * 4);
+  if (dx_bf16) VITA_REQUIRE(ld_dxb % 4 == 0 && ld_dxb <= lddx);
+  const int nblk = (int)vita_layernorm_bwd_nblk(rows);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, lddy, dy_dtype == VITA_DT_F32, x,
+                     ldx, gamma, mean, rstd, dx_in, dx_out, lddx, (uint16_t*)dx_bf16, ld_dxb, partial, rows, (int)d);
+  VITA_CHECK_LAUNCH("vita_layernorm_bwd");
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial,
+                     nblk, (int)d, dgamma, dbeta);
+  VITA_CHECK_LAUNCH("vita_layernorm_bwd_reduce");
+  return VITA_OK;
+}
+
+// ------------------------------------------------------------------------------------- argsort + mask
+// rank[i] = #{j : key_j < key_i  or (key_j == key_i and j < i)}  == ids_restore[i]; ids_shuffle[rank[i]] = i.
+// Keys are the order-preserving uint32 image of the float noise; exact and stable by construction.
+__device__ __forceinline__ uint32_t float_key(float f) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__global__ __launch_bounds__(256) void argsort_rank_kernel(const float* __restrict__ noise, int l, int len_keep,
+                                                           int64_t* __restrict__ ids_shuffle,
+                                                           int64_t* __restrict__ ids_restore, float* __restrict__ mask) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t* keys = reinterpret_cast<uint32_t*>(smem);
+  const int row = blockIdx.y;
+  const float* nr = noise + (int64_t)row * l;
+  const int lp = (l + 3) & ~3;
+  for (int j = threadIdx.x; j < lp; j += 256) keys[j] = j < l ? float_key(nr[j]) : 0xffffffffu;
+  __syncthreads();
+  const int i0 = blockIdx.x * 256, i = i0 + threadIdx.x;
+  const uint32_t ki = i < l ? keys[i] : 0u;
+  int cnt = 0;
+  const int jb = i0 & ~3;                              // [0, jb): j < every i of this block
+  int je = (i0 + 256 + 3) & ~3; if (je > lp) je = lp;   // [je, lp): j > every i of this block
+  for (int j = 0; j < jb; j += 4) {
+    const u32x4 k4 = *reinterpret_cast<const u32x4*>(keys + j);
+    cnt += (k4[0] <= ki) + (k4[1] <= ki) + (k4[2] <= ki) + (k4[3] <= ki);
+  }
+  for (int j = jb; j < je; ++j) { const uint32_t kj = keys[j]; cnt += (kj < ki) || (kj == ki && j < i); }
+  for (int j = je; j < lp; j += 4) {
+    const u32x4 k4 = *reinterpret_cast<const u32x4*>(keys + j);
+    cnt += (k4[0] < ki) + (k4[1] < ki) + (k4[2] < ki) + (k4[3] < ki);
+  }
+  if (i < l) {
+    ids_restore[(int64_t)row * l + i] = cnt;
+    ids_shuffle[(int64_t)row * l + cnt] = i;
+    mask[(int64_t)row * l + i] = cnt < len_keep ? 0.f : 1.f;
+  }
+}
+
+extern "C" int vita_argsort_mask(const float* noise, int64_t n, int64_t l, int64_t len_keep, int64_t* ids_shuffle,
+                                 int64_t* ids_restore, float* mask, void* stream) {
+  VITA_REQUIRE(noise && ids_shuffle && ids_restore && mask);
+  VITA_REQUIRE(n > 0 && n < 65536 && l > 0 && l <= 32768 && len_keep >= 0 && len_keep <= l);
+  const size_t lds = (size_t)((l + 3) & ~3) * 4;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)argsort_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr = true; }
+  hipLaunchKernelGGL(argsort_rank_kernel, dim3((unsigned)((l + 255) / 256), (unsigned)n), dim3(256), lds, (hipStream_t)stream,
+                     noise, (int)l, (int)len_keep, ids_shuffle, ids_restore, mask);
+  VITA_CHECK_LAUNCH("vita_argsort_mask");
+  return VITA_OK;
+}
+
+// ------------------------------------------------------------------------------------- gather / scatter
+__global__ __launch_bounds__(256) void row_gather_kernel(const float* __restrict__ x, int64_t ldx, int64_t l_in,
+                                                         const int64_t* __restrict__ ids, int64_t ld_ids,
+                                                         const float* __restrict__ fill, float* __restrict__ out,
+                                                         int64_t ldo, int64_t l_out, int d) {
+  const int64_t j = blockIdx.x, b = blockIdx.y;
+  const int64_t src = ids[b * ld_ids + j];
+  float* o = out + (b * l_out + j) * ldo;
+  if (src < l_in) {
+    const float* s = x + (b * l_in + src) * ldx;
+    for (int c = threadIdx.x * 4; c < ldo; c += 1024) {
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < d) { v = *reinterpret_cast<const f32x4*>(s + c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (c + r >= d) v[r] = 0.f; }
+      *reinterpret_cast<f32x4*>(o + c) = v;
+    }
+  } else {
+    for (int c = threadIdx.x * 4; c < ldo; c += 1024) {
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (fill && c + r < d) ? fill[c + r] : 0.f;
+      *reinterpret_cast<f32x4*>(o + c) = v;
+    }
+  }
+}
+extern "C" int vita_row_gather_f32(const float* x, int64_t ldx, int64_t l_in, const int64_t* ids, int64_t ld_ids,
+                                   const float* fill, float* out, int64_t ldo, int64_t l_out, int64_t nb, int64_t d,
+                                   void* stream) {
+  VITA_REQUIRE(x && ids && out && nb > 0 && nb < 65536 && l_out > 0 && d > 0);
+  VITA_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ldx >= ((d + 3) / 4) * 4 && ldo >= d);
+  VITA_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0);
+  hipLaunchKernelGGL(row_gather_kernel, dim3((unsigned)l_out, (unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     l_in, ids, ld_ids, fill, out, ldo, l_out, (int)d);
+  VITA_CHECK_LAUNCH("vita_row_gather_f32");
+  return VITA_OK;
+}
+
+__global__ __launch_bounds__(256) void row_scatter_kernel(const float* __restrict__ dout, int64_t ldo, int64_t l_out,
+                                                          const int64_t* __restrict__ ids, int64_t ld_ids,
+                                                          float* __restrict__ dx, int64_t ldx, int64_t l_in,
+                                                          float* __restrict__ dfill, int d) {
+  const int64_t j = blockIdx.x, b = blockIdx.y;
+  const int64_t dst = ids[b * ld_ids + j];
+  const float* s = dout + (b * l_out + j) * ldo;
+  if (dst < l_in) {
+    float* o = dx + (b * l_in + dst) * ldx;
+    for (int c = threadIdx.x * 4; c < ldx; c += 1024) {
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < d) { v = *reinterpret_cast<const f32x4*>(s + c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (c + r >= d) v[r] = 0.f; }
+      *reinterpret_cast<f32x4*>(o + c) = v;
+    }
+  } else if (dfill) {
+    for (int c = threadIdx.x; c < d; c += 256) atomicAdd(dfill + c, s[c]);
+  }
+}
+extern "C" int vita_row_scatter_f32(const float* dout, int64_t ldo, int64_t l_out, const int64_t* ids, int64_t ld_ids,
+                                    float* dx, int64_t ldx, int64_t l_in, float* dfill, int64_t nb, int64_t d,
+                                    void* stream) {
+  VITA_REQUIRE(dout && ids && dx && nb > 0 && nb < 65536 && l_out > 0 && d > 0);
+  VITA_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ldo >= ((d + 3) / 4) * 4 && ldx >= d);
+  VITA_REQUIRE(((uintptr_t)dx & 15) == 0 && ((uintptr_t)dout & 15) == 0);
+  hipLaunchKernelGGL(row_scatter_kernel, dim3((unsigned)l_out, (unsigned)nb), dim3(256), 0, (hipStream_t)stream, dout, ldo,
+                     l_out, ids, ld_ids, dx, ldx, l_in, dfill, (int)d);
+  VITA_CHECK_LAUNCH("vita_row_scatter_f32");
+  return VITA_OK;
+}
+
+// ------------------------------------------------------------------------------------- im2col + assemble
+// one wave per token; unit = 4 consecutive pixels along W (pw % 4 == 0, W % 4 == 0)
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, int S, int T, int H, int W, int pt,
+                                                     int ph, int pw, const int64_t* __restrict__ ids, int64_t n_tok,
+                                                     uint16_t* __restrict__ out, int64_t ldo, int64_t total) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= total) return;
+  const int64_t b = tok / n_tok, j = tok % n_tok;
+  const int64_t id = ids ? ids[b * n_tok + j] : j;
+  const int t = T / pt, h = H / ph, w = W / pw;
+  const int wi = (int)(id % w); int64_t r = id / w;
+  const int hi = (int)(r % h); r /= h;
+  const int ti = (int)(r % t); const int s = (int)(r / t);
+  const float* base = img + (((b * S + s) * T + (int64_t)ti * pt) * H + (int64_t)hi * ph) * W + (int64_t)wi * pw;
+  const int P = pt * ph * pw, upr = pw >> 2;   // units per pixel row
+  uint16_t* o = out + tok * ldo;
+  for (int u = lane; u * 4 < ldo; u += 64) {
+    const int e = u * 4;
+    u32x2 pk = u32x2{0u, 0u};
+    if (e < P) {
+      const int rowi = u / upr, cu = u % upr;     // rowi = p_t*ph + p_h
+      const int p_t = rowi / ph, p_h = rowi % ph;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(base + ((int64_t)p_t * H + p_h) * W + cu * 4);
+      pk = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    }
+    *reinterpret_cast<u32x2*>(o + e) = pk;
+  }
+}
+extern "C" int vita_im2col_bf16(const float* img, int64_t nb, int64_t S, int64_t T, int64_t H, int64_t W, int64_t pt,
+                                int64_t ph, int64_t pw, const int64_t* ids, int64_t n_tok, void* out, int64_t ldo,
+                                void* stream) {
+  VITA_REQUIRE(img && out && nb > 0 && n_tok > 0);
+  VITA_REQUIRE(pw % 4 == 0 && W % 4 == 0 && T % pt == 0 && H % ph == 0 && W % pw == 0);
+  VITA_REQUIRE(ldo % 8 == 0 && ldo >= pt * ph * pw && ((uintptr_t)img & 15) == 0 && ((uintptr_t)out & 15) == 0);
+  const int64_t total = nb * n_tok;
+  hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, img, (int)S,
+                     (int)T, (int)H, (int)W, (int)pt, (int)ph, (int)pw, ids, n_tok, (uint16_t*)out, ldo, total);
+  VITA_CHECK_LAUNCH("vita_im2col_bf16");
+  return VITA_OK;
+}
+
+__global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__ y, int64_t ldy, const float* __restrict__ cls,
+                                                       const float* __restrict__ pos, const int64_t* __restrict__ ids,
+                                                       int64_t n_tok, int d, float* __restrict__ out, int64_t ldo) {
+  const int64_t r = blockIdx.x, b = blockIdx.y;   // r in [0, 1+n_tok)
+  float* o = out + (b * (n_tok + 1) + r) * ldo;
+  const float* src; const float* pe = nullptr;
+  if (r == 0) { src = cls; if (pos) pe = pos; }
+  else {
+    src = y + (b * n_tok + (r - 1)) * ldy;
+    if (pos) pe = pos + (1 + (ids ? ids[b * n_tok + r - 1] : r - 1)) * (int64_t)d;
+  }
+  for (int c = threadIdx.x; c < ldo; c += 256) o[c] = c < d ? src[c] + (pe ? pe[c] : 0.f) : 0.f;
+}
+extern "C" int vita_tokens_assemble(const float* y, int64_t ldy, const float* cls, const float* pos, const int64_t* ids,
+                                    int64_t nb, int64_t n_tok, int64_t d, float* out, int64_t ldo, void* stream) {
+  VITA_REQUIRE(y && cls && out && nb > 0 && nb < 65536 && n_tok > 0 && d > 0 && ldo >= d && ldy >= d);
+  hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)(n_tok + 1), (unsigned)nb), dim3(256), 0, (hipStream_t)stream, y, ldy,
+                     cls, pos, ids, n_tok, (int)d, out, ldo);
+  VITA_CHECK_LAUNCH("vita_tokens_assemble");
+  return VITA_OK;
+}
+
+// ------------------------------------------------------------------------------------- cast / colsum
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, int64_t ldx, uint16_t* __restrict__ y,
+                                                   int64_t ldy, int64_t rows, int d) {
+  const int64_t units = ldy >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * units; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / units; const int c = (int)(i % units) * 4;
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < d) { v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (c + k >= d) v[k] = 0.f; }
+    *reinterpret_cast<u32x2*>(y + r * ldy + c) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+  }
+}
+extern "C" int vita_cast_f32_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int64_t d, void* stream) {
+  VITA_REQUIRE(x && y && rows > 0 && d > 0 && ldx % 4 == 0 && ldy % 4 == 0 && ldy >= d && ldx >= ((d + 3) / 4) * 4);
+  int64_t nb = (rows * (ldy >> 2) + 255) / 256; if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(cast_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, ldx, (uint16_t*)y, ldy, rows, (int)d);
+  VITA_CHECK_LAUNCH("vita_cast_f32_bf16");
+  return VITA_OK;
+}
+
+// each thread owns 2 adjacent columns; grid.y row chunks; fp32 atomics into a zeroed output
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, int f32, int64_t ld, int64_t rows,
+                                                     int64_t cols, float* __restrict__ out, int64_t rows_per_blk) {
+  const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (c >= cols) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_blk;
+  int64_t r1 = r0 + rows_per_blk; if (r1 > rows) r1 = rows;
+  float a0 = 0.f, a1 = 0.f;
+  if (f32) {
+    const float* p = (const float*)x;
+    for (int64_t r = r0; r < r1; ++r) { a0 += p[r * ld + c]; if (c + 1 < cols) a1 += p[r * ld + c + 1]; }
+  } else {
+    const uint16_t* p = (const uint16_t*)x;
+    for (int64_t r = r0; r < r1; ++r) {
+      const uint32_t u = *reinterpret_cast<const uint32_t*>(p + r * ld + c);
+      a0 += bf16_bits_to_f32((uint16_t)(u & 0xffff)); a1 += bf16_bits_to_f32((uint16_t)(u >> 16));
+    }
+  }
+  atomicAdd(out + c, a0);
+  if (c + 1 < cols) atomicAdd(out + c + 1, a1);
+}
+extern "C" int vita_colsum(const void* x, int32_t dtype, int64_t ld, int64_t rows, int64_t cols, float* out, void* stream) {
+  VITA_REQUIRE(x && out && rows > 0 && cols > 0 && ld % 2 == 0 && ld >= ((cols + 1) / 2) * 2);
+  if (hipMemsetAsync(out, 0, cols * sizeof(float), (hipStream_t)stream) != hipSuccess) return VITA_ERR_LAUNCH;
+  int64_t chunks = (rows + 127) / 128; if (chunks > 256) chunks = 256;
+  const int64_t rpb = (rows + chunks - 1) / chunks;
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((cols + 511) / 512), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, x,
+                     dtype == VITA_DT_F32, ld, rows, cols, out, rpb);
+  VITA_CHECK_LAUNCH("vita_colsum");
+  return VITA_OK;
+}
+
+// ------------------------------------------------------------------------------------- softmax rows (materialised attention)
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* red) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < 4; ++i) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+  return r;
+}
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, int64_t lds_, uint16_t* __restrict__ p,
+                                                           int64_t ldp, int n, float scale) {
+  __shared__ float red[4];
+  const float* sr = s + (int64_t)blockIdx.x * lds_;
+  uint16_t* pr = p + (int64_t)blockIdx.x * ldp;
+  float m = -INFINITY;
+  for (int j = threadIdx.x; j < n; j += 256) m = fmaxf(m, sr[j]);
+  m = block_reduce(m, true, red);
+  float z = 0.f;
+  for (int j = threadIdx.x; j < n; j += 256) z += __expf((sr[j] - m) * scale);
+  z = block_reduce(z, false, red);
+  const float inv = 1.f / z;
+  for (int j = threadIdx.x; j < ldp; j += 256) pr[j] = j < n ? f32_to_bf16_bits(__expf((sr[j] - m) * scale) * inv) : (uint16_t)0;
+}
+extern "C" int vita_softmax_rows(const float* s, int64_t lds_, void* p, int64_t ldp, int64_t rows, int64_t n, float scale,
+                                 void* stream) {
+  VITA_REQUIRE(s && p && rows > 0 && n > 0 && ldp >= n && lds_ >= n && rows < (1ll << 31));
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, lds_, (uint16_t*)p, ldp,
+                     (int)n, scale);
+  VITA_CHECK_LAUNCH("vita_softmax_rows");
+  return VITA_OK;
+}
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const uint16_t* __restrict__ p, int64_t ldp,
+                                                               const float* __restrict__ dp, int64_t lddp,
+                                                               uint16_t* __restrict__ ds, int64_t ldds, int n, float scale) {
+  __shared__ float red[4];
+  const uint16_t* pr = p + (int64_t)blockIdx.x * ldp;
+  const float* dpr = dp + (int64_t)blockIdx.x * lddp;
+  uint16_t* dsr = ds + (int64_t)blockIdx.x * ldds;
+  float dot = 0.f;
+  for (int j = threadIdx.x; j < n; j += 256) dot += bf16_bits_to_f32(pr[j]) * dpr[j];
+  dot = block_reduce(dot, false, red);
+  for (int j = threadIdx.x; j < ldds; j += 256)
+    dsr[j] = j < n ? f32_to_bf16_bits(bf16_bits_to_f32(pr[j]) * (dpr[j] - dot) * scale) : (uint16_t)0;
+}
+extern "C" int vita_softmax_bwd_rows(const void* p, int64_t ldp, const float* dp, int64_t lddp, void* ds, int64_t ldds,
+                                     int64_t rows, int64_t n, float scale, void* stream) {
+  VITA_REQUIRE(p && dp && ds && rows > 0 && n > 0 && ldp >= n && lddp >= n && ldds >= n && rows < (1ll << 31));
+  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)p, ldp,
+                     dp, lddp, (uint16_t*)ds, ldds, (int)n, scale);
+  VITA_CHECK_LAUNCH("vita_softmax_bwd_rows");
+  return VITA_OK;
+}
+
+// ------------------------------------------------------------------------------------- weight shadows
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, int64_t rows_log, int64_t cols_log,
+                                                          uint16_t* __restrict__ out, int64_t rows_phys, int64_t ld_phys,
+                                                          int rsp, int rsl, int csp, int csl) {
+  const int64_t total = rows_phys * ld_phys;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / ld_phys, c = i % ld_phys;
+    const int64_t lr = seg_map(r, rsp, rsl), lc = seg_map(c, csp, csl);
+    float v = 0.f;
+    if (lr >= 0 && lr < rows_log && lc >= 0 && lc < cols_log) v = w[lr * cols_log + lc];
+    out[i] = f32_to_bf16_bits(v);
+  }
+}
+extern "C" int vita_pack_weight_bf16(const float* w, int64_t rows_log, int64_t cols_log, void* out, int64_t rows_phys,
+                                     int64_t ld_phys, int32_t rsp, int32_t rsl, int32_t csp, int32_t csl, void* stream) {
+  VITA_REQUIRE(w && out && rows_log > 0 && cols_log > 0 && rows_phys > 0 && ld_phys > 0);
+  int64_t nb = (rows_phys * ld_phys + 255) / 256; if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, w, rows_log, cols_log,
+                     (uint16_t*)out, rows_phys, ld_phys, rsp, rsl, csp, csl);
+  VITA_CHECK_LAUNCH("vita_pack_weight_bf16");
+  return VITA_OK;
+}
+__global__ void pack_vec_kernel(const float* __restrict__ v, int64_t n_log, float* __restrict__ out, int64_t n_phys, int sp, int sl) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_phys) return;
+  const int64_t li = seg_map(i, sp, sl);
+  out[i] = (li >= 0 && li < n_log) ? v[li] : 0.f;
+}
+extern "C" int vita_pack_vec_f32(const float* v, int64_t n_log, float* out, int64_t n_phys, int32_t sp, int32_t sl, void* stream) {
+  VITA_REQUIRE(v && out && n_log > 0 && n_phys > 0);
+  hipLaunchKernelGGL(pack_vec_kernel, dim3((unsigned)((n_phys + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, n_log, out, n_phys, sp, sl);
+  VITA_CHECK_LAUNCH("vita_pack_vec_f32");
+  return VITA_OK;
+}
+__global__ void unpack_vec_kernel(const float* __restrict__ v, int64_t n_phys, float* __restrict__ out, int64_t n_log, int sp, int sl) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_phys) return;
+  const int64_t li = seg_map(i, sp, sl);
+  if (li >= 0 && li < n_log) out[li] = v[i];
+}
+extern "C" int vita_unpack_vec_f32(const float* v, int64_t n_phys, float* out, int64_t n_log, int32_t sp, int32_t sl, void* stream) {
+  VITA_REQUIRE(v && out && n_log > 0 && n_phys > 0);
+  hipLaunchKernelGGL(unpack_vec_kernel, dim3((unsigned)((n_phys + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, n_phys, out, n_log, sp, sl);
+  VITA_CHECK_LAUNCH("vita_unpack_vec_f32");
+  return VITA_OK;
+}
+
+// ------------------------------------------------------------------------------------- Adam
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                   float wd, float gscale, float bc1, float bc2_sqrt) {
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    if (i + 4 <= n) {
+      f32x4 pv = *reinterpret_cast<f32x4*>(p + i), gv = *reinterpret_cast<const f32x4*>(g + i);
+      f32x4 mv = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float gr = gv[r] * gscale + wd * pv[r];
+        mv[r] = b1 * mv[r] + (1.f - b1) * gr;
+        vv[r] = b2 * vv[r] + (1.f - b2) * gr * gr;
+        pv[r] -= (lr / bc1) * mv[r] / (sqrtf(vv[r]) / bc2_sqrt + eps);
+      }
+      *reinterpret_cast<f32x4*>(p + i) = pv; *reinterpret_cast<f32x4*>(m + i) = mv; *reinterpret_cast<f32x4*>(v + i) = vv;
+    } else {
+      for (int64_t k = i; k < n; ++k) {
+        float gr = g[k] * gscale + wd * p[k];
+        m[k] = b1 * m[k] + (1.f - b1) * gr;
+        v[k] = b2 * v[k] + (1.f - b2) * gr * gr;
+        p[k] -= (lr / bc1) * m[k] / (sqrtf(v[k]) / bc2_sqrt + eps);
+      }
+    }
+  }
+}
+extern "C" int vita_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, float grad_scale, int64_t step, void* stream) {
+  VITA_REQUIRE(p && g && m && v && n > 0 && step >= 1);
+  VITA_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2 = 1.f - powf(beta2, (float)step);
+  int64_t nb = (n / 4 + 255) / 256; if (nb > 4096) nb = 4096; if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                     weight_decay, grad_scale, bc1, sqrtf(bc2));
+  VITA_CHECK_LAUNCH("vita_adam_step");
+  return VITA_OK;
+}

@@ -1,0 +1,207 @@
+"""Thin torch-tensor wrappers over the C ABI (include/vita_hip.h).  PyTorch only provides device
+memory and the stream; every computation happens in libvita_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, check
+
+BF16, F32 = 0, 1
+EPI_NONE, EPI_GELU, EPI_RESIDUAL, EPI_GELU_BWD = 0, 1, 2, 3
+
+
+def rup(x: int, m: int) -> int:
+    return (int(x) + m - 1) // m * m
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def gemm(a, b, c, m, n, k, lda, ldb, ldc, *, a_layout=0, b_layout=0, bias=None, epilogue=EPI_NONE,
+         aux_in=None, aux_out=None, ld_aux=0, alpha=1.0, split_k=1, batch=(1, 1),
+         a_strides=(0, 0), b_strides=(0, 0), c_strides=(0, 0), row_seg=(0, 0), col_seg=(0, 0),
+         a_off=0, b_off=0, c_off=0):
+    """C[m,n] = epi(alpha * A(m,k) B(k,n)); a/b bf16 tensors, c bf16|fp32.  *_off are element offsets."""
+    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
+    d = GemmDesc()
+    d.a = a.data_ptr() + 2 * a_off
+    d.b = b.data_ptr() + 2 * b_off
+    d.c = c.data_ptr() + c.element_size() * c_off
+    d.bias = _p(bias); d.aux_in = _p(aux_in); d.aux_out = _p(aux_out)
+    d.m, d.n, d.k = m, n, k
+    d.lda, d.ldb, d.ldc, d.ld_aux = lda, ldb, ldc, ld_aux
+    d.batch_outer, d.batch_inner = batch
+    d.a_stride_outer, d.a_stride_inner = a_strides
+    d.b_stride_outer, d.b_stride_inner = b_strides
+    d.c_stride_outer, d.c_stride_inner = c_strides
+    d.a_layout, d.b_layout = a_layout, b_layout
+    d.c_dtype = _dt(c); d.epilogue = epilogue; d.split_k = split_k
+    d.row_seg_phys, d.row_seg_log = row_seg
+    d.col_seg_phys, d.col_seg_log = col_seg
+    d.alpha = alpha
+    check(_lib.lib().vita_gemm_bf16(C.byref(d), _s()), "vita_gemm_bf16")
+    return c
+
+
+def pack_weight(w: torch.Tensor, rows_phys: int, ld_phys: int, row_seg=(0, 0), col_seg=(0, 0), out=None):
+    w = w.detach()
+    assert w.dtype == torch.float32 and w.is_contiguous()
+    rows_log, cols_log = w.shape[0], w[0].numel()
+    if out is None:
+        out = torch.empty(rows_phys, ld_phys, dtype=torch.bfloat16, device=w.device)
+    check(_lib.lib().vita_pack_weight_bf16(w.data_ptr(), rows_log, cols_log, out.data_ptr(), rows_phys, ld_phys,
+                                           row_seg[0], row_seg[1], col_seg[0], col_seg[1], _s()), "pack_weight")
+    return out
+
+
+def pack_vec(v: torch.Tensor, n_phys: int, seg=(0, 0), out=None):
+    v = v.detach()
+    if out is None:
+        out = torch.empty(n_phys, dtype=torch.float32, device=v.device)
+    check(_lib.lib().vita_pack_vec_f32(v.data_ptr(), v.numel(), out.data_ptr(), n_phys, seg[0], seg[1], _s()), "pack_vec")
+    return out
+
+
+def unpack_vec(v: torch.Tensor, n_log: int, seg=(0, 0)):
+    out = torch.zeros(n_log, dtype=torch.float32, device=v.device)
+    check(_lib.lib().vita_unpack_vec_f32(v.data_ptr(), v.numel(), out.data_ptr(), n_log, seg[0], seg[1], _s()), "unpack_vec")
+    return out
+
+
+def layernorm_fwd(x, ldx, gamma, beta, rows, d, ldy, out_dtype=torch.bfloat16, eps=1e-5):
+    y = torch.empty(rows, ldy, dtype=out_dtype, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(_lib.lib().vita_layernorm_fwd(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), ldy, _dt(y),
+                                        mean.data_ptr(), rstd.data_ptr(), rows, d, eps, _s()), "layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, lddy, x, ldx, gamma, mean, rstd, rows, d, lddx, dx_in=None, want_bf16=False, ld_dxb=0):
+    dev = x.device
+    dx = torch.empty(rows, lddx, dtype=torch.float32, device=dev)
+    dxb = torch.empty(rows, ld_dxb, dtype=torch.bfloat16, device=dev) if want_bf16 else None
+    nblk = _lib.lib().vita_layernorm_bwd_nblk(rows)
+    partial = torch.empty(2 * nblk * d, dtype=torch.float32, device=dev)
+    dgamma = torch.empty(d, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(d, dtype=torch.float32, device=dev)
+    check(_lib.lib().vita_layernorm_bwd(dy.data_ptr(), lddy, _dt(dy), x.data_ptr(), ldx, gamma.data_ptr(), mean.data_ptr(),
+                                        rstd.data_ptr(), _p(dx_in), dx.data_ptr(), lddx, _p(dxb), ld_dxb,
+                                        dgamma.data_ptr(), dbeta.data_ptr(), partial.data_ptr(), rows, d, _s()), "layernorm_bwd")
+    return dx, dxb, dgamma, dbeta
+
+
+def argsort_mask(noise: torch.Tensor, len_keep: int):
+    n, l = noise.shape
+    assert noise.dtype == torch.float32 and noise.is_contiguous()
+    ids_shuffle = torch.empty(n, l, dtype=torch.int64, device=noise.device)
+    ids_restore = torch.empty(n, l, dtype=torch.int64, device=noise.device)
+    mask = torch.empty(n, l, dtype=torch.float32, device=noise.device)
+    check(_lib.lib().vita_argsort_mask(noise.data_ptr(), n, l, len_keep, ids_shuffle.data_ptr(), ids_restore.data_ptr(),
+                                       mask.data_ptr(), _s()), "argsort_mask")
+    return ids_shuffle, ids_restore, mask
+
+
+def row_gather(x, ldx, l_in, ids, ld_ids, l_out, nb, d, ldo, fill=None):
+    out = torch.empty(nb, l_out, ldo, dtype=torch.float32, device=x.device)
+    check(_lib.lib().vita_row_gather_f32(x.data_ptr(), ldx, l_in, ids.data_ptr(), ld_ids, _p(fill), out.data_ptr(), ldo,
+                                         l_out, nb, d, _s()), "row_gather")
+    return out
+
+
+def row_scatter(dout, ldo, l_out, ids, ld_ids, l_in, nb, d, ldx, want_dfill=False):
+    dx = torch.zeros(nb, l_in, ldx, dtype=torch.float32, device=dout.device)
+    dfill = torch.zeros(d, dtype=torch.float32, device=dout.device) if want_dfill else None
+    check(_lib.lib().vita_row_scatter_f32(dout.data_ptr(), ldo, l_out, ids.data_ptr(), ld_ids, dx.data_ptr(), ldx, l_in,
+                                          _p(dfill), nb, d, _s()), "row_scatter")
+    return dx, dfill
+
+
+def im2col(img, patch, ids, n_tok, ldo):
+    nb, S, T, H, W = img.shape
+    assert img.dtype == torch.float32 and img.is_contiguous()
+    out = torch.empty(nb * n_tok, ldo, dtype=torch.bfloat16, device=img.device)
+    check(_lib.lib().vita_im2col_bf16(img.data_ptr(), nb, S, T, H, W, patch[0], patch[1], patch[2], _p(ids), n_tok,
+                                      out.data_ptr(), ldo, _s()), "im2col")
+    return out
+
+
+def tokens_assemble(y, ldy, cls, pos, ids, nb, n_tok, d, ldo):
+    out = torch.empty(nb, n_tok + 1, ldo, dtype=torch.float32, device=y.device)
+    check(_lib.lib().vita_tokens_assemble(y.data_ptr(), ldy, cls.data_ptr(), _p(pos), _p(ids), nb, n_tok, d,
+                                          out.data_ptr(), ldo, _s()), "tokens_assemble")
+    return out
+
+
+def cast_bf16(x, ldx, rows, d, ldy):
+    y = torch.empty(rows, ldy, dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().vita_cast_f32_bf16(x.data_ptr(), ldx, y.data_ptr(), ldy, rows, d, _s()), "cast")
+    return y
+
+
+def colsum(x, ld, rows, cols):
+    out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    check(_lib.lib().vita_colsum(x.data_ptr(), _dt(x), ld, rows, cols, out.data_ptr(), _s()), "colsum")
+    return out
+
+
+def softmax_rows(s, lds, p, ldp, rows, n, scale):
+    check(_lib.lib().vita_softmax_rows(s.data_ptr(), lds, p.data_ptr(), ldp, rows, n, scale, _s()), "softmax_rows")
+
+
+def softmax_bwd_rows(p, ldp, dp, lddp, ds, ldds, rows, n, scale):
+    check(_lib.lib().vita_softmax_bwd_rows(p.data_ptr(), ldp, dp.data_ptr(), lddp, ds.data_ptr(), ldds, rows, n, scale, _s()),
+          "softmax_bwd_rows")
+
+
+def l2_normalize_fwd(x, eps=1e-12):
+    rows, d = x.shape
+    y = torch.empty_like(x); inv = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(_lib.lib().vita_l2_normalize_fwd(x.data_ptr(), rows, d, eps, y.data_ptr(), inv.data_ptr(), _s()), "l2norm_fwd")
+    return y, inv
+
+
+def l2_normalize_bwd(dy, y, inv):
+    rows, d = y.shape
+    dx = torch.empty_like(y)
+    check(_lib.lib().vita_l2_normalize_bwd(dy.data_ptr(), y.data_ptr(), inv.data_ptr(), rows, d, dx.data_ptr(), _s()), "l2norm_bwd")
+    return dx
+
+
+def sgemm(a, b, c, m, n, k, lda, ldb, ldc, a_layout=0, b_layout=0, alpha=1.0, beta=0.0):
+    check(_lib.lib().vita_sgemm_f32(a.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, lda, ldb, ldc, a_layout, b_layout,
+                                    alpha, beta, _s()), "sgemm")
+    return c
+
+
+def ce_rows(logits, ld, rows, cols, label_offset, weight, loss, dlogits=None, row_lse=None):
+    check(_lib.lib().vita_ce_rows(logits.data_ptr(), ld, rows, cols, label_offset, weight, loss.data_ptr(), _p(row_lse),
+                                  _p(dlogits), ld if dlogits is None else dlogits.stride(0), _s()), "ce_rows")
+
+
+def sigmoid_mse_patch(z, ldz, img, patch, mask, inv_count, loss, pred=None, dz=None, ld_dz=0):
+    nb, S, T, H, W = img.shape
+    check(_lib.lib().vita_sigmoid_mse_patch(z.data_ptr(), ldz, img.data_ptr(), nb, S, T, H, W, patch[0], patch[1], patch[2],
+                                            _p(mask), inv_count, _p(pred), loss.data_ptr(), _p(dz), ld_dz, _s()), "sigmoid_mse_patch")
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, grad_scale, step):
+    check(_lib.lib().vita_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
+                                    weight_decay, grad_scale, step, _s()), "adam_step")
