@@ -118,10 +118,12 @@ int vita_argsort_mask(const float* noise, int64_t n, int64_t l, int64_t len_keep
  * torch.gather(x, 1, ids[...,None].repeat(1,1,D)) (utils/imaging_model_related.py:246) on fp32
  * rows: out[b][j] = x[b][ids[b][j]];  rows with ids >= l_in take `fill` (decoder mask-token
  * un-shuffle, networks/imaging_decoders.py:288-291) or zero when fill == NULL.
- * x [nb][l_in][ldx], out [nb][l_out][ldo], ids int64 [nb][l_out] with row stride ld_ids. */
+ * x [nb][l_in][ldx], out [nb][l_out][ldo], ids int64 [nb][l_out] with row stride ld_ids.
+ * pos (optional fp32 [l_out][d]) is added to output row j (the decoder's `+ dec_pos_embed`,
+ * networks/imaging_decoders.py:292-295). */
 int vita_row_gather_f32(const float* x, int64_t ldx, int64_t l_in, const int64_t* ids,
-                        int64_t ld_ids, const float* fill, float* out, int64_t ldo, int64_t l_out,
-                        int64_t nb, int64_t d, void* stream);
+                        int64_t ld_ids, const float* fill, const float* pos, float* out, int64_t ldo,
+                        int64_t l_out, int64_t nb, int64_t d, void* stream);
 /* backward of the gather for unique ids: dx[b][ids[b][j]] = dout[b][j]; dx must be pre-zeroed.
  * Rows with ids >= l_in are summed into dfill (fp32 [d], pre-zeroed, may be NULL). */
 int vita_row_scatter_f32(const float* dout, int64_t ldo, int64_t l_out, const int64_t* ids,
@@ -132,16 +134,17 @@ int vita_row_scatter_f32(const float* dout, int64_t ldo, int64_t l_out, const in
  * PatchEmbed.forward (networks/tokenizers.py:38-56) = im2col of the selected tokens (bf16) ->
  * vita_gemm_bf16 -> vita_tokens_assemble.
  * img fp32 [nb][S][T][H][W]; token id = ((s*t + ti)*h + hi)*w + wi; patch vector order (pt,ph,pw).
- * ids int64 [nb][n_tok] (NULL = identity, n_tok = L).  out bf16 [nb*n_tok][ldo], pads zero. */
+ * ids int64 [nb][n_tok] (NULL = identity, n_tok = L).  Token (b,j) is written to row
+ * b*out_batch_rows + out_row0 + j of out (bf16 [..][ldo], pads zero); other rows are untouched. */
 int vita_im2col_bf16(const float* img, int64_t nb, int64_t S, int64_t T, int64_t H, int64_t W,
                      int64_t pt, int64_t ph, int64_t pw, const int64_t* ids, int64_t n_tok,
-                     void* out, int64_t ldo, void* stream);
-/* x[b][0] = cls + pos[0];  x[b][1+j] = y[b*n_tok+j] + pos[1 + ids[b][j]]
- * (networks/imaging_encoders.py:91-106).  y fp32 [nb*n_tok][ldy]; pos fp32 [1+L][d] or NULL;
- * out fp32 [nb][1+n_tok][ldo] with zero pads. */
+                     void* out, int64_t ldo, int64_t out_batch_rows, int64_t out_row0, void* stream);
+/* x[b][0] = cls + pos[0];  x[b][1+j] = y[b*y_batch_rows + j] + pos[1 + ids[b][j]]
+ * (networks/imaging_encoders.py:91-106).  y fp32 rows of ldy; pos fp32 [1+L][d] or NULL;
+ * out fp32 [nb][1+n_tok][ldo] with zero pads.  out may alias y row-for-row (in place). */
 int vita_tokens_assemble(const float* y, int64_t ldy, const float* cls, const float* pos,
                          const int64_t* ids, int64_t nb, int64_t n_tok, int64_t d, float* out,
-                         int64_t ldo, void* stream);
+                         int64_t ldo, int64_t y_batch_rows, void* stream);
 
 /* ------------------------------------------------------------------ misc row ops */
 /* fp32 [rows][ldx] -> bf16 [rows][ldy], cols [d,ldy) zero */

@@ -1,0 +1,215 @@
+"""GPU parity of the assembled hot path (encoder / decoder / Stage-I step / CLIP loss) against the
+CPU oracle on identical weights, inputs and mask noise.  Index outputs are bit-exact; bf16 MFMA
+activations, losses and gradients are held to rtol 2e-2 (relative L2 per tensor), fp32 paths to 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vita_oracle as O  # noqa: E402
+
+CFG = dict(patch_size=(5, 8, 8), enc_embed_dim=129, enc_depth=2, enc_num_heads=3, dec_embed_dim=129, dec_depth=1,
+           dec_num_heads=3, mlp_ratio=4.0, mask_ratio=0.7, mask_type="random", use_enc_pe=True, circular_pe=False,
+           patch_embed_cls="PatchEmbed", patch_in_channels=1, mask_loss=False, lr=1e-4, loss_types=["mse"], val_dset=None)
+IMG = (9, 10, 32, 32)
+L_TOK = 288
+KEEP = int(L_TOK * (1 - 0.7))
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+
+
+def build(cfg=CFG, img=IMG, seed=1):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from vita_amd.train import ReconMAE
+    p = O.init_stage1_params(img_shape=img, patch_size=cfg["patch_size"], enc_dim=cfg["enc_embed_dim"],
+                             enc_depth=cfg["enc_depth"], enc_heads=cfg["enc_num_heads"], dec_dim=cfg["dec_embed_dim"],
+                             dec_depth=cfg["dec_depth"], dec_heads=cfg["dec_num_heads"], seed=seed)
+    # non-trivial biases / LN affine so that every gradient path is exercised
+    g = torch.Generator().manual_seed(7)
+    for k in p:
+        if k.endswith(".bias"):
+            p[k] = torch.randn(p[k].shape, generator=g) * 0.05
+        if "norm" in k and k.endswith(".weight"):
+            p[k] = 1 + torch.randn(p[k].shape, generator=g) * 0.05
+    model = ReconMAE(img_shape=list(img), use_both_axes=True, **cfg)
+    missing = model.load_state_dict(p, strict=True)
+    return model.cuda(), p
+
+
+def draw_noise(seed, n, l):
+    torch.manual_seed(seed)
+    noise = torch.rand(n, l, device="cuda").cpu().numpy()
+    torch.manual_seed(seed)
+    return noise
+
+
+def ocfg(cfg=CFG):
+    return dict(patch_size=cfg["patch_size"], enc_depth=cfg["enc_depth"], enc_heads=cfg["enc_num_heads"],
+                dec_depth=cfg["dec_depth"], dec_heads=cfg["dec_num_heads"], mask_ratio=cfg["mask_ratio"])
+
+
+def test_encoder_forward_and_indices():
+    model, p = build()
+    torch.manual_seed(0)
+    imgs = torch.rand(2, *IMG)
+    noise = draw_noise(123, 2, L_TOK)
+    x, mask, ids = model.encoder_imaging(imgs.cuda())
+    xr, mr, ir = O.encoder_forward(imgs, p, patch_size=CFG["patch_size"], num_heads=3, depth=2, mask_ratio=0.7,
+                                   noise=noise, prefix="encoder_imaging.")
+    assert x.shape == xr.shape == (2, 1 + KEEP, 129)
+    assert torch.equal(mask.cpu(), mr) and torch.equal(ids.cpu(), ir) and ids.dtype == torch.int64
+    assert rel(x, xr) < 2e-2
+    # unmasked long-sequence entry point
+    model.encoder_imaging.using_masker = False
+    y, hidden = model.encoder_imaging.forward_with_skip_connection(imgs.cuda())
+    yr, hr = O.encoder_forward_with_skip(imgs, p, patch_size=CFG["patch_size"], num_heads=3, depth=2, prefix="encoder_imaging.")
+    assert rel(y, yr) < 2e-2 and len(hidden) == 2
+    for h, r in zip(hidden, hr):
+        assert h.shape == r.shape and rel(h, r) < 2e-2
+    x2, m2, i2 = model.encoder_imaging(imgs.cuda())
+    assert m2 is None and i2 is None and rel(x2, yr) < 2e-2
+
+
+def test_patch_embed_golden(golden):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from vita_amd.networks import PatchEmbed
+    g = golden("g1_patch_embed.npz")
+    for tag, im, D in (("a", [9, 10, 16, 16], 17), ("b", [9, 5, 32, 32], 129)):
+        pe = PatchEmbed(im, in_channels=1, patch_size=[5, 8, 8], out_channels=D).cuda()
+        with torch.no_grad():
+            pe.proj.weight.copy_(torch.from_numpy(g[f"{tag}_w"])); pe.proj.bias.copy_(torch.from_numpy(g[f"{tag}_b"]))
+        assert tuple(pe.grid_size) == tuple(g[f"{tag}_grid"]) and int(pe.num_patches) == int(g[f"{tag}_num_patches"])
+        y = pe(torch.from_numpy(g[f"{tag}_x"]).cuda())
+        assert rel(y, torch.from_numpy(g[f"{tag}_y"])) < 2e-2
+        (y * torch.from_numpy(g[f"{tag}_cot"]).cuda()).sum().backward()
+        assert rel(pe.proj.weight.grad, torch.from_numpy(g[f"{tag}_dw"])) < 2e-2
+        assert rel(pe.proj.bias.grad, torch.from_numpy(g[f"{tag}_db"])) < 2e-2
+
+
+def test_masker_dropin(golden):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from vita_amd.networks import Masker
+    g = golden("g4_gather.npz")
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    noise = draw_noise(7, 2, 64)
+    xm, mask, ids = Masker("random", 0.7, None)(x)
+    xr, mr, ir = O.masker_call(torch.from_numpy(g["x"]), noise, 0.7)
+    assert torch.equal(xm.cpu(), xr) and torch.equal(mask.cpu(), mr) and torch.equal(ids.cpu(), ir)
+    (xm * torch.from_numpy(g["cot"]).cuda()[:, :xm.shape[1]]).sum().backward()
+    assert x.grad.shape == x.shape
+    with pytest.raises(NotImplementedError):
+        Masker("block", 0.5, None)
+
+
+def test_stage1_step_vs_oracle():
+    model, p = build()
+    torch.manual_seed(3)
+    imgs = torch.rand(2, *IMG)
+    from vita_amd.train import FlatAdam, stage1_train_step
+    opt = FlatAdam(model.parameters(), lr=1e-4)
+    noise = draw_noise(55, 2, L_TOK)
+    loss = stage1_train_step(model, opt, imgs.cuda())
+    state = {}
+    p_ref = {k: v.clone() for k, v in p.items()}
+    loss_ref, grads_ref = O.stage1_train_step(imgs, p_ref, noise, state, lr=1e-4, **ocfg())
+    assert abs(loss.item() - loss_ref.item()) / loss_ref.item() < 2e-2
+    named = dict(model.named_parameters())
+    worst = 0.0
+    for k, gr in grads_ref.items():
+        e = rel(named[k].grad, gr)
+        worst = max(worst, e)
+        assert e < 3e-2, (k, e)
+    # Adam-updated weights: each element moved by ~lr; compare the update direction
+    for k in grads_ref:
+        upd = named[k].detach().cpu() - p[k]
+        upd_ref = p_ref[k] - p[k]
+        assert torch.allclose(named[k].detach().cpu(), p_ref[k], atol=2.5e-4), k
+        if upd_ref.norm() > 0:
+            cos = torch.nn.functional.cosine_similarity(upd.flatten(), upd_ref.flatten(), dim=0)
+            assert cos > 0.9, (k, cos)
+    # second step runs on refreshed bf16 weight shadows
+    loss2 = stage1_train_step(model, opt, imgs.cuda())
+    assert torch.isfinite(loss2)
+
+
+def test_dropin_forward_and_checkpointing():
+    model, p = build()
+    torch.manual_seed(4)
+    imgs = torch.rand(2, *IMG)
+    noise = draw_noise(9, 2, L_TOK)
+    pred, mask = model(imgs.cuda())
+    loss_ref, pred_ref, mask_ref = O.stage1_loss(imgs, p, noise, **ocfg())
+    assert pred.shape == pred_ref.shape == (2, L_TOK, 320) and torch.equal(mask.cpu(), mask_ref)
+    assert rel(pred, pred_ref) < 2e-2
+    # activation checkpointing (torch.utils.checkpoint, non re-entrant) gives the same gradients
+    torch.manual_seed(9)
+    l1, _, _ = model.training_loss(imgs.cuda()); l1.backward()
+    g1 = {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None}
+    model.zero_grad()
+    model.encoder_imaging.grad_checkpointing = True
+    model.decoder_imaging.decoder.grad_checkpointing = True
+    torch.manual_seed(9)
+    l2, _, _ = model.training_loss(imgs.cuda()); l2.backward()
+    assert torch.allclose(l1, l2, rtol=1e-6)
+    for k, v in model.named_parameters():
+        if v.grad is not None:
+            assert rel(v.grad, g1[k]) < 1e-3, k
+
+
+def test_block_reference_dims():
+    """One Block at the reference dims (D=1025, 5 heads of 205, hidden 4100), fwd + all grads."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from vita_amd.nn import Block
+    torch.manual_seed(0)
+    D, H, N, B = 1025, 5, 197, 2
+    p = {}
+    O.init_block(p, "", D, 4 * D, torch.Generator().manual_seed(5))
+    g = torch.Generator().manual_seed(6)
+    for k in p:
+        if k.endswith("bias"):
+            p[k] = torch.randn(p[k].shape, generator=g) * 0.05
+    blk = Block(D, H, 4.0, qkv_bias=True).cuda()
+    blk.load_state_dict(p, strict=True)
+    x = torch.randn(B, N, D)
+    cot = torch.randn(B, N, D)
+    xg = x.cuda().requires_grad_(True)
+    y = blk(xg)
+    (y * cot.cuda()).sum().backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = O.block_forward(xr, leaves, "", H)
+    (yr * cot).sum().backward()
+    assert rel(y, yr) < 2e-2
+    assert rel(xg.grad, xr.grad) < 2e-2
+    for k, v in blk.named_parameters():
+        assert rel(v.grad, leaves[k].grad) < 2e-2, k
+
+
+def test_clip_loss_golden(golden):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from vita_amd.losses import CLIPLoss
+    g = golden("g5_clip.npz")
+    for B in (4, 8, 256):
+        for lam in (0.5, 0.3):
+            key = f"B{B}_l{int(lam * 10)}"
+            a = torch.from_numpy(g[f"a_{key}"]).cuda().requires_grad_(True)
+            b = torch.from_numpy(g[f"b_{key}"]).cuda().requires_grad_(True)
+            loss, logits, labels = CLIPLoss(0.1, lam)(a, b)
+            loss.backward()
+            torch.testing.assert_close(loss.cpu(), torch.from_numpy(g[f"loss_{key}"]), rtol=1e-4, atol=1e-5)
+            assert np.array_equal(labels.cpu().numpy(), g[f"labels_{key}"]) and labels.dtype == torch.int64
+            torch.testing.assert_close(a.grad.cpu(), torch.from_numpy(g[f"da_{key}"]), rtol=1e-4, atol=1e-6)
+            torch.testing.assert_close(b.grad.cpu(), torch.from_numpy(g[f"db_{key}"]), rtol=1e-4, atol=1e-6)
+            if B <= 8:
+                torch.testing.assert_close(logits.cpu(), torch.from_numpy(g[f"logits_{key}"]), rtol=1e-4, atol=1e-5)
+    with pytest.raises(ValueError):
+        CLIPLoss(0.1, 1.5)

@@ -41,10 +41,10 @@ SIGNATURES = {
     "vita_layernorm_bwd_nblk": [i64],
     "vita_layernorm_bwd": [vp, i64, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, i64, vp],
     "vita_argsort_mask": [vp, i64, i64, i64, vp, vp, vp, vp],
-    "vita_row_gather_f32": [vp, i64, i64, vp, i64, vp, vp, i64, i64, i64, i64, vp],
+    "vita_row_gather_f32": [vp, i64, i64, vp, i64, vp, vp, vp, i64, i64, i64, i64, vp],
     "vita_row_scatter_f32": [vp, i64, i64, vp, i64, vp, i64, i64, vp, i64, i64, vp],
-    "vita_im2col_bf16": [vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, i64, vp, i64, vp],
-    "vita_tokens_assemble": [vp, i64, vp, vp, vp, i64, i64, i64, vp, i64, vp],
+    "vita_im2col_bf16": [vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, i64, vp, i64, i64, i64, vp],
+    "vita_tokens_assemble": [vp, i64, vp, vp, vp, i64, i64, i64, vp, i64, i64, vp],
     "vita_cast_f32_bf16": [vp, i64, vp, i64, i64, i64, vp],
     "vita_colsum": [vp, i32, i64, i64, i64, vp, vp],
     "vita_softmax_rows": [vp, i64, vp, i64, i64, i64, f32, vp],
@@ -55,12 +55,9 @@ SIGNATURES = {
     "vita_ce_rows": [vp, i64, i64, i64, i64, f32, vp, vp, vp, i64, vp],
     "vita_sigmoid_mse_patch": [vp, i64, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, f32, vp, vp, vp, i64, vp],
     "vita_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, i64, vp],
-    "vita_attn_fwd": [vp, vp, vp, i64, i64, i64, i64, i64, i64, f32, vp],
-    "vita_attn_bwd_workspace": [i64, i64, i64, i64],
-    "vita_attn_bwd": [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, f32, vp],
 }
-_I64_RET = {"vita_layernorm_bwd_nblk", "vita_attn_bwd_workspace"}
-OPTIONAL = {"vita_attn_fwd", "vita_attn_bwd", "vita_attn_bwd_workspace"}
+_I64_RET = {"vita_layernorm_bwd_nblk"}
+OPTIONAL = set()
 
 _lib = None
 

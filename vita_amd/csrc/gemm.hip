@@ -65,7 +65,10 @@ struct Stager {
       }
     } else {
       // whole remaining matrix from column free0: rows k >= K fall outside -> zeros
-      int64_t bytes = (Ktot * ld - free0) * 2;
+      // rows < K-1 may wrap into the next row (in bounds, feeds discarded outputs only); the last
+      // row ends exactly at nfree so nothing past the operand is ever touched
+      int64_t nfree8 = (nfree + 7) & ~(int64_t)7; if (nfree8 > ld) nfree8 = ld;   // whole 16-B chunks
+      int64_t bytes = ((Ktot - 1) * ld + (nfree8 - free0)) * 2;
       rs = make_rsrc(base + free0, (uint32_t)bytes);
       kstep = (uint32_t)(BK * ld * 2);
 #pragma unroll

@@ -232,37 +232,38 @@ extern "C" int vita_argsort_mask(const float* noise, int64_t n, int64_t l, int64
 // ------------------------------------------------------------------------------------- gather / scatter
 __global__ __launch_bounds__(256) void row_gather_kernel(const float* __restrict__ x, int64_t ldx, int64_t l_in,
                                                          const int64_t* __restrict__ ids, int64_t ld_ids,
-                                                         const float* __restrict__ fill, float* __restrict__ out,
-                                                         int64_t ldo, int64_t l_out, int d) {
+                                                         const float* __restrict__ fill, const float* __restrict__ pos,
+                                                         float* __restrict__ out, int64_t ldo, int64_t l_out, int d) {
   const int64_t j = blockIdx.x, b = blockIdx.y;
   const int64_t src = ids[b * ld_ids + j];
   float* o = out + (b * l_out + j) * ldo;
+  const float* pe = pos ? pos + j * (int64_t)d : nullptr;
   if (src < l_in) {
     const float* s = x + (b * l_in + src) * ldx;
     for (int c = threadIdx.x * 4; c < ldo; c += 1024) {
       f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
       if (c < d) { v = *reinterpret_cast<const f32x4*>(s + c);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (c + r >= d) v[r] = 0.f; }
+        for (int r = 0; r < 4; ++r) { if (c + r >= d) v[r] = 0.f; else if (pe) v[r] += pe[c + r]; } }
       *reinterpret_cast<f32x4*>(o + c) = v;
     }
   } else {
     for (int c = threadIdx.x * 4; c < ldo; c += 1024) {
       f32x4 v;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = (fill && c + r < d) ? fill[c + r] : 0.f;
+      for (int r = 0; r < 4; ++r) v[r] = (c + r < d) ? (fill ? fill[c + r] : 0.f) + (pe ? pe[c + r] : 0.f) : 0.f;
       *reinterpret_cast<f32x4*>(o + c) = v;
     }
   }
 }
 extern "C" int vita_row_gather_f32(const float* x, int64_t ldx, int64_t l_in, const int64_t* ids, int64_t ld_ids,
-                                   const float* fill, float* out, int64_t ldo, int64_t l_out, int64_t nb, int64_t d,
-                                   void* stream) {
+                                   const float* fill, const float* pos, float* out, int64_t ldo, int64_t l_out,
+                                   int64_t nb, int64_t d, void* stream) {
   VITA_REQUIRE(x && ids && out && nb > 0 && nb < 65536 && l_out > 0 && d > 0);
   VITA_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ldx >= ((d + 3) / 4) * 4 && ldo >= d);
   VITA_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0);
   hipLaunchKernelGGL(row_gather_kernel, dim3((unsigned)l_out, (unsigned)nb), dim3(256), 0, (hipStream_t)stream, x, ldx,
-                     l_in, ids, ld_ids, fill, out, ldo, l_out, (int)d);
+                     l_in, ids, ld_ids, fill, pos, out, ldo, l_out, (int)d);
   VITA_CHECK_LAUNCH("vita_row_gather_f32");
   return VITA_OK;
 }
@@ -303,7 +304,8 @@ extern "C" int vita_row_scatter_f32(const float* dout, int64_t ldo, int64_t l_ou
 // one wave per token; unit = 4 consecutive pixels along W (pw % 4 == 0, W % 4 == 0)
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, int S, int T, int H, int W, int pt,
                                                      int ph, int pw, const int64_t* __restrict__ ids, int64_t n_tok,
-                                                     uint16_t* __restrict__ out, int64_t ldo, int64_t total) {
+                                                     uint16_t* __restrict__ out, int64_t ldo, int64_t total,
+                                                     int64_t out_batch_rows, int64_t out_row0) {
   const int lane = threadIdx.x & 63;
   const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tok >= total) return;
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
   const int ti = (int)(r % t); const int s = (int)(r / t);
   const float* base = img + (((b * S + s) * T + (int64_t)ti * pt) * H + (int64_t)hi * ph) * W + (int64_t)wi * pw;
   const int P = pt * ph * pw, upr = pw >> 2;   // units per pixel row
-  uint16_t* o = out + tok * ldo;
+  uint16_t* o = out + (b * out_batch_rows + out_row0 + j) * ldo;
   for (int u = lane; u * 4 < ldo; u += 64) {
     const int e = u * 4;
     u32x2 pk = u32x2{0u, 0u};
@@ -330,35 +332,38 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
 }
 extern "C" int vita_im2col_bf16(const float* img, int64_t nb, int64_t S, int64_t T, int64_t H, int64_t W, int64_t pt,
                                 int64_t ph, int64_t pw, const int64_t* ids, int64_t n_tok, void* out, int64_t ldo,
-                                void* stream) {
+                                int64_t out_batch_rows, int64_t out_row0, void* stream) {
   VITA_REQUIRE(img && out && nb > 0 && n_tok > 0);
   VITA_REQUIRE(pw % 4 == 0 && W % 4 == 0 && T % pt == 0 && H % ph == 0 && W % pw == 0);
+  VITA_REQUIRE(out_batch_rows >= out_row0 + n_tok && out_row0 >= 0);
   VITA_REQUIRE(ldo % 8 == 0 && ldo >= pt * ph * pw && ((uintptr_t)img & 15) == 0 && ((uintptr_t)out & 15) == 0);
   const int64_t total = nb * n_tok;
   hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, img, (int)S,
-                     (int)T, (int)H, (int)W, (int)pt, (int)ph, (int)pw, ids, n_tok, (uint16_t*)out, ldo, total);
+                     (int)T, (int)H, (int)W, (int)pt, (int)ph, (int)pw, ids, n_tok, (uint16_t*)out, ldo, total, out_batch_rows, out_row0);
   VITA_CHECK_LAUNCH("vita_im2col_bf16");
   return VITA_OK;
 }
 
 __global__ __launch_bounds__(256) void assemble_kernel(const float* __restrict__ y, int64_t ldy, const float* __restrict__ cls,
                                                        const float* __restrict__ pos, const int64_t* __restrict__ ids,
-                                                       int64_t n_tok, int d, float* __restrict__ out, int64_t ldo) {
+                                                       int64_t n_tok, int d, float* __restrict__ out, int64_t ldo,
+                                                       int64_t y_batch_rows) {
   const int64_t r = blockIdx.x, b = blockIdx.y;   // r in [0, 1+n_tok)
   float* o = out + (b * (n_tok + 1) + r) * ldo;
   const float* src; const float* pe = nullptr;
   if (r == 0) { src = cls; if (pos) pe = pos; }
   else {
-    src = y + (b * n_tok + (r - 1)) * ldy;
+    src = y + (b * y_batch_rows + (r - 1)) * ldy;
     if (pos) pe = pos + (1 + (ids ? ids[b * n_tok + r - 1] : r - 1)) * (int64_t)d;
   }
   for (int c = threadIdx.x; c < ldo; c += 256) o[c] = c < d ? src[c] + (pe ? pe[c] : 0.f) : 0.f;
 }
 extern "C" int vita_tokens_assemble(const float* y, int64_t ldy, const float* cls, const float* pos, const int64_t* ids,
-                                    int64_t nb, int64_t n_tok, int64_t d, float* out, int64_t ldo, void* stream) {
+                                    int64_t nb, int64_t n_tok, int64_t d, float* out, int64_t ldo, int64_t y_batch_rows,
+                                    void* stream) {
   VITA_REQUIRE(y && cls && out && nb > 0 && nb < 65536 && n_tok > 0 && d > 0 && ldo >= d && ldy >= d);
   hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)(n_tok + 1), (unsigned)nb), dim3(256), 0, (hipStream_t)stream, y, ldy,
-                     cls, pos, ids, n_tok, (int)d, out, ldo);
+                     cls, pos, ids, n_tok, (int)d, out, ldo, y_batch_rows);
   VITA_CHECK_LAUNCH("vita_tokens_assemble");
   return VITA_OK;
 }

@@ -1,0 +1,133 @@
+"""Loss mirrors: CLIPLoss (utils/clip_loss.py:6-40) with optional cross-GPU negatives, and the fused
+sigmoid + MSE reconstruction criterion (utils/losses.py:92-140 'mse' branch on the patchified image,
+utils/imaging_model_related.py:103-117)."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from . import ops
+from .nn import _require_cuda
+
+
+class _ClipFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out0, out1, tau, lam0, group, grad_world_scale):
+        out0 = out0.float().contiguous(); out1 = out1.float().contiguous()
+        Bl, d = out0.shape
+        a, ia = ops.l2_normalize_fwd(out0)
+        b, ib = ops.l2_normalize_fwd(out1)
+        world, rank = (dist.get_world_size(group), dist.get_rank(group)) if group is not None else (1, 0)
+        if world > 1:
+            packed = torch.stack([a, b])                                  # one message for both towers
+            gathered = torch.empty(world, 2, Bl, d, dtype=torch.float32, device=a.device)
+            dist.all_gather_into_tensor(gathered, packed, group=group)
+            a_all = gathered[:, 0].reshape(world * Bl, d).contiguous()
+            b_all = gathered[:, 1].reshape(world * Bl, d).contiguous()
+        else:
+            a_all, b_all = a, b
+        Bg, off = world * Bl, rank * Bl
+        l_it = torch.empty(Bl, Bg, dtype=torch.float32, device=a.device)
+        l_ti = torch.empty(Bl, Bg, dtype=torch.float32, device=a.device)
+        ops.sgemm(a, b_all, l_it, Bl, Bg, d, d, d, Bg, 0, 0, alpha=1.0 / tau)
+        ops.sgemm(b, a_all, l_ti, Bl, Bg, d, d, d, Bg, 0, 0, alpha=1.0 / tau)
+        loss = torch.zeros(1, dtype=torch.float32, device=a.device)
+        d_it = torch.empty_like(l_it); d_ti = torch.empty_like(l_ti)
+        ops.ce_rows(l_it, Bg, Bl, Bg, off, lam0 / Bg, loss, dlogits=d_it)
+        ops.ce_rows(l_ti, Bg, Bl, Bg, off, (1.0 - lam0) / Bg, loss, dlogits=d_ti)
+        if world > 1:
+            dist.all_reduce(loss, group=group)                           # report the global-batch loss
+        ctx.save_for_backward(a, b, ia, ib, a_all, b_all, d_it, d_ti)
+        ctx.meta = (tau, group, world, Bl, Bg, d, grad_world_scale)
+        labels = off + torch.arange(Bl, device=a.device)
+        ctx.mark_non_differentiable(l_it, labels)
+        return loss[0], l_it, labels
+
+    @staticmethod
+    def backward(ctx, gloss, _gl, _glab):
+        a, b, ia, ib, a_all, b_all, d_it, d_ti = ctx.saved_tensors
+        tau, group, world, Bl, Bg, d, gws = ctx.meta
+        dev = a.device
+        da = torch.empty(Bl, d, dtype=torch.float32, device=dev)
+        db = torch.empty(Bl, d, dtype=torch.float32, device=dev)
+        # direct terms: rows of this rank's logits
+        ops.sgemm(d_it, b_all, da, Bl, d, Bg, Bg, d, d, 0, 1, alpha=1.0 / tau)
+        ops.sgemm(d_ti, a_all, db, Bl, d, Bg, Bg, d, d, 0, 1, alpha=1.0 / tau)
+        # terms through the (gathered) other operand: d a_all += d_ti^T b ; d b_all += d_it^T a
+        if world > 1:
+            cross = torch.empty(2, Bg, d, dtype=torch.float32, device=dev)
+            ops.sgemm(d_ti, b, cross[0], Bg, d, Bl, Bg, d, d, 1, 1, alpha=1.0 / tau)
+            ops.sgemm(d_it, a, cross[1], Bg, d, Bl, Bg, d, d, 1, 1, alpha=1.0 / tau)
+            send = cross.view(2, world, Bl, d).permute(1, 0, 2, 3).contiguous()
+            recv = torch.empty(2, Bl, d, dtype=torch.float32, device=dev)
+            dist.reduce_scatter_tensor(recv, send, group=group)          # backward of the all-gather
+            da += recv[0]; db += recv[1]
+        else:
+            ops.sgemm(d_ti, b, da, Bg, d, Bl, Bg, d, d, 1, 1, alpha=1.0 / tau, beta=1.0)
+            ops.sgemm(d_it, a, db, Bg, d, Bl, Bg, d, d, 1, 1, alpha=1.0 / tau, beta=1.0)
+        g0 = ops.l2_normalize_bwd(da, a, ia)
+        g1 = ops.l2_normalize_bwd(db, b, ib)
+        s = gloss * gws
+        return g0 * s, g1 * s, None, None, None, None
+
+
+class CLIPLoss(nn.Module):
+    """Same constructor / return tuple as the reference.  With ``group`` set (or
+    ``gather_distributed=True`` and torch.distributed initialised) every rank scores its local rows
+    against the all-gathered other tower; the returned loss is the loss of the concatenated global
+    batch, ``logits`` is [B_local, B_global] and ``labels = rank*B_local + arange(B_local)``.
+    ``ddp_average=True`` pre-multiplies gradients by world_size so that DDP's 1/world averaging yields
+    exactly the gradient of the global-batch loss."""
+
+    def __init__(self, temperature: float, lambda_0: float = 0.5, gather_distributed: bool = False, group=None,
+                 ddp_average: bool = True) -> None:
+        super().__init__()
+        self.temperature = temperature
+        if lambda_0 > 1 or lambda_0 < 0:
+            raise ValueError('lambda_0 must be a float between 0 and 1.')
+        self.lambda_0 = lambda_0
+        self.lambda_1 = 1 - lambda_0
+        self.gather_distributed = gather_distributed
+        self.group = group
+        self.ddp_average = ddp_average
+
+    def forward(self, out0: torch.Tensor, out1: torch.Tensor) -> Tuple:
+        _require_cuda(out0)
+        group = self.group
+        if group is None and self.gather_distributed and dist.is_available() and dist.is_initialized():
+            group = dist.group.WORLD
+        world = dist.get_world_size(group) if group is not None else 1
+        return _ClipFn.apply(out0, out1, float(self.temperature), float(self.lambda_0), group if world > 1 else None,
+                             float(world) if (self.ddp_average and world > 1) else 1.0)
+
+
+class _ReconMSEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, imgs, mask, patch, P, want_pred):
+        B, L1, ldz = z.shape
+        imgs = imgs.float().contiguous()
+        L = L1 - 1
+        count = (mask.sum().item() if mask is not None else B * L) * P
+        loss = torch.zeros(1, dtype=torch.float32, device=z.device)
+        dz = torch.empty(B * L1, ldz, dtype=torch.bfloat16, device=z.device)
+        pred = torch.empty(B, L, P, dtype=torch.float32, device=z.device) if want_pred else None
+        ops.sigmoid_mse_patch(z.contiguous(), ldz, imgs, patch, mask, 1.0 / count, loss, pred=pred, dz=dz, ld_dz=ldz)
+        ctx.save_for_backward(dz)
+        ctx.shape = (B, L1, ldz)
+        if want_pred:
+            ctx.mark_non_differentiable(pred)
+            return loss[0], pred
+        return loss[0], None
+
+    @staticmethod
+    def backward(ctx, gloss, _gp):
+        (dz,) = ctx.saved_tensors
+        return (dz.float() * gloss).view(ctx.shape), None, None, None, None, None
+
+
+def recon_mse_from_logits(z, imgs, patch_size, P, mask=None, mask_loss=False, want_pred=False):
+    """z: pre-sigmoid head output [B, 1+L, ldz] (row 0 = cls).  Returns (loss, pred|None)."""
+    return _ReconMSEFn.apply(z, imgs, mask if mask_loss else None, tuple(int(p) for p in patch_size), int(P), want_pred)

@@ -1,0 +1,341 @@
+"""Host-side mirror of the transformer pieces on the hot path: a timm-0.6.12-compatible ``Block``
+(call sites networks/imaging_encoders.py:36-40, networks/imaging_decoders.py:43-45) whose forward and
+backward run entirely in libvita_hip.so.
+
+Data layout in HBM:
+  * residual stream  : fp32 [B, N, Dp]   Dp = round_up(D, 64), pad columns are always zero
+  * GEMM operands    : bf16, leading dims multiples of 8; q/k/v and the attention output are stored
+                       head-padded: head h occupies columns [h*hdp, h*hdp+hd), hdp = round_up(hd, 32)
+  * weights          : fp32 nn.Parameters with the reference shapes (state_dict compatible) plus
+                       padded bf16 "shadows" refreshed whenever the parameter changes.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import ops
+
+_SHADOW_EPOCH = 0
+
+
+def bump_shadow_epoch():
+    """Call after parameters were modified outside torch's version tracking (our Adam kernel)."""
+    global _SHADOW_EPOCH
+    _SHADOW_EPOCH += 1
+
+
+class Dims:
+    def __init__(self, dim: int, num_heads: int, hidden: int):
+        assert dim % num_heads == 0
+        self.D, self.H, self.hd, self.hidden = dim, num_heads, dim // num_heads, hidden
+        self.Dp = ops.rup(dim, 64)
+        self.hdp = ops.rup(self.hd, 32)
+        self.AO = self.H * self.hdp            # attention-output / q / k / v width (head padded)
+        self.QKV = 3 * self.AO
+        self.Hp = ops.rup(hidden, 64)
+        self.scale = self.hd ** -0.5
+
+
+class _Shadows:
+    """bf16 padded copies of fp32 parameters, keyed by (version, epoch, data_ptr)."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, name, param, build):
+        key = (param._version, _SHADOW_EPOCH, param.data_ptr())
+        hit = self._c.get(name)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = (key, build(param))
+            self._c[name] = hit
+        return hit[1]
+
+
+def pad_tokens(x: torch.Tensor, Dp: int) -> torch.Tensor:
+    """[B,N,D] fp32 -> contiguous [B,N,Dp] with zero pads (plumbing at the drop-in boundary)."""
+    B, N, D = x.shape
+    xp = torch.zeros(B, N, Dp, dtype=torch.float32, device=x.device)
+    xp[..., :D] = x
+    return xp
+
+
+class Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.act = nn.GELU()
+        self.drop1 = nn.Identity()
+        self.fc2 = nn.Linear(hidden, dim)
+        self.drop2 = nn.Identity()
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads, qkv_bias):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Identity()
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Identity()
+
+
+# ----------------------------------------------------------------------------- attention (bf16 MFMA)
+def attention_fwd(qkv, B, N, dm: Dims, use_flash: bool):
+    """qkv bf16 [B*N, QKV] -> (o bf16 [B*N, AO], saved)."""
+    dev = qkv.device
+    H, hdp, AO, QKV = dm.H, dm.hdp, dm.AO, dm.QKV
+    o = torch.empty(B * N, AO, dtype=torch.bfloat16, device=dev)
+    if use_flash:
+        lse = torch.empty(B, H, N, dtype=torch.float32, device=dev)
+        ops.attn_fwd(qkv, o, lse, B, N, H, dm.hd, hdp, dm.scale)
+        return o, ("flash", lse)
+    Nld = ops.rup(N, 8)
+    s = torch.empty(B, H, N, Nld, dtype=torch.float32, device=dev)
+    ops.gemm(qkv, qkv, s, N, N, hdp, QKV, QKV, Nld, batch=(B, H), a_strides=(N * QKV, hdp),
+             b_strides=(N * QKV, hdp), c_strides=(H * N * Nld, N * Nld), b_off=AO)
+    p = torch.empty(B, H, N, Nld, dtype=torch.bfloat16, device=dev)
+    ops.softmax_rows(s, Nld, p, Nld, B * H * N, N, dm.scale)
+    del s
+    ops.gemm(p, qkv, o, N, hdp, N, Nld, QKV, AO, b_layout=1, batch=(B, H), a_strides=(H * N * Nld, N * Nld),
+             b_strides=(N * QKV, hdp), c_strides=(N * AO, hdp), b_off=2 * AO)
+    return o, ("mat", p)
+
+
+def attention_bwd(do, qkv, o, saved, B, N, dm: Dims):
+    """do bf16 [B*N, AO] -> dqkv bf16 [B*N, QKV] (pads zero)."""
+    dev = qkv.device
+    H, hdp, AO, QKV = dm.H, dm.hdp, dm.AO, dm.QKV
+    dqkv = torch.empty(B * N, QKV, dtype=torch.bfloat16, device=dev)
+    if saved[0] == "flash":
+        ops.attn_bwd(qkv, o, do, saved[1], dqkv, B, N, H, dm.hd, hdp, dm.scale)
+        return dqkv
+    p = saved[1]
+    Nld = p.shape[-1]
+    bs_qkv, bs_p, bs_o = (N * QKV, hdp), (H * N * Nld, N * Nld), (N * AO, hdp)
+    dp = torch.empty(B, H, N, Nld, dtype=torch.float32, device=dev)
+    # dP = dO V^T
+    ops.gemm(do, qkv, dp, N, N, hdp, AO, QKV, Nld, batch=(B, H), a_strides=bs_o, b_strides=bs_qkv, c_strides=bs_p,
+             b_off=2 * AO)
+    # dV = P^T dO
+    ops.gemm(p, do, dqkv, N, hdp, N, Nld, AO, QKV, a_layout=1, b_layout=1, batch=(B, H), a_strides=bs_p,
+             b_strides=bs_o, c_strides=bs_qkv, c_off=2 * AO)
+    ds = torch.empty(B, H, N, Nld, dtype=torch.bfloat16, device=dev)
+    ops.softmax_bwd_rows(p, Nld, dp, Nld, ds, Nld, B * H * N, N, dm.scale)
+    del dp
+    # dQ = dS K ; dK = dS^T Q
+    ops.gemm(ds, qkv, dqkv, N, hdp, N, Nld, QKV, QKV, b_layout=1, batch=(B, H), a_strides=bs_p, b_strides=bs_qkv,
+             c_strides=bs_qkv, b_off=AO)
+    ops.gemm(ds, qkv, dqkv, N, hdp, N, Nld, QKV, QKV, a_layout=1, b_layout=1, batch=(B, H), a_strides=bs_p,
+             b_strides=bs_qkv, c_strides=bs_qkv, c_off=AO)
+    return dqkv
+
+
+def _split_k_for(m, n, k):
+    tiles = ((m + 127) // 128) * ((n + 127) // 128)
+    kt = (k + 63) // 64
+    s = max(1, min(8, (2 * 256 + tiles - 1) // tiles, kt // 4 if kt >= 4 else 1))
+    return s
+
+
+def wgrad(dy, lddy, x, ldx, rows_out, cols_out, k_tokens, row_seg=(0, 0), col_seg=(0, 0), m_phys=None, n_phys=None):
+    """dW[logical rows_out, cols_out] fp32 = dy^T x over k_tokens rows (both operands k-strided)."""
+    m = m_phys if m_phys is not None else rows_out
+    n = n_phys if n_phys is not None else cols_out
+    sk = _split_k_for(m, n, k_tokens)
+    out = (torch.zeros if sk > 1 else torch.empty)(rows_out, cols_out, dtype=torch.float32, device=dy.device)
+    ops.gemm(dy, x, out, m, n, k_tokens, lddy, ldx, cols_out, a_layout=1, b_layout=1, split_k=sk,
+             row_seg=row_seg, col_seg=col_seg)
+    return out
+
+
+# ----------------------------------------------------------------------------- Block
+class _BlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xp, blk, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b):
+        dm: Dims = blk.dims
+        B, N, Dp = xp.shape
+        M = B * N
+        sh = blk.shadows()
+        x = xp.reshape(M, Dp)
+        ln1, mean1, rstd1 = ops.layernorm_fwd(x, Dp, n1w, n1b, M, dm.D, Dp, eps=blk.norm1.eps)
+        qkv = torch.empty(M, dm.QKV, dtype=torch.bfloat16, device=x.device)
+        ops.gemm(ln1, sh["qkv_w"], qkv, M, dm.QKV, Dp, Dp, Dp, dm.QKV, bias=sh["qkv_b"])
+        o, att_saved = attention_fwd(qkv, B, N, dm, blk.use_flash)
+        x1 = torch.empty(M, Dp, dtype=torch.float32, device=x.device)
+        ops.gemm(o, sh["proj_w"], x1, M, Dp, dm.AO, dm.AO, dm.AO, Dp, bias=sh["proj_b"], epilogue=ops.EPI_RESIDUAL,
+                 aux_in=x, ld_aux=Dp)
+        ln2, mean2, rstd2 = ops.layernorm_fwd(x1, Dp, n2w, n2b, M, dm.D, Dp, eps=blk.norm2.eps)
+        u = torch.empty(M, dm.Hp, dtype=torch.bfloat16, device=x.device)
+        g = torch.empty(M, dm.Hp, dtype=torch.bfloat16, device=x.device)
+        ops.gemm(ln2, sh["fc1_w"], g, M, dm.Hp, Dp, Dp, Dp, dm.Hp, bias=sh["fc1_b"], epilogue=ops.EPI_GELU, aux_out=u)
+        x2 = torch.empty(M, Dp, dtype=torch.float32, device=x.device)
+        ops.gemm(g, sh["fc2_w"], x2, M, Dp, dm.Hp, dm.Hp, dm.Hp, Dp, bias=sh["fc2_b"], epilogue=ops.EPI_RESIDUAL,
+                 aux_in=x1, ld_aux=Dp)
+        ctx.blk = blk
+        ctx.shape = (B, N)
+        ctx.att_saved = att_saved
+        ctx.save_for_backward(x, mean1, rstd1, ln1, qkv, o, x1, mean2, rstd2, ln2, u, g, n1w, n2w)
+        return x2.view(B, N, Dp)
+
+    @staticmethod
+    def backward(ctx, dx2):
+        blk = ctx.blk
+        dm: Dims = blk.dims
+        B, N = ctx.shape
+        M, Dp, D = B * N, dm.Dp, dm.D
+        x, mean1, rstd1, ln1, qkv, o, x1, mean2, rstd2, ln2, u, g, n1w, n2w = ctx.saved_tensors
+        sh = blk.shadows()
+        dx2 = dx2.contiguous().view(M, Dp)
+        dyb = ops.cast_bf16(dx2, Dp, M, D, Dp)
+        # ---- MLP
+        d_fc2w = wgrad(dyb, Dp, g, dm.Hp, D, dm.hidden, M)
+        d_fc2b = ops.colsum(dyb, Dp, M, D)
+        du = torch.empty(M, dm.Hp, dtype=torch.bfloat16, device=x.device)
+        ops.gemm(dyb, sh["fc2_w"], du, M, dm.Hp, Dp, Dp, dm.Hp, dm.Hp, b_layout=1, epilogue=ops.EPI_GELU_BWD, aux_in=u,
+                 ld_aux=dm.Hp)
+        d_fc1w = wgrad(du, dm.Hp, ln2, Dp, dm.hidden, D, M)
+        d_fc1b = ops.colsum(du, dm.Hp, M, dm.hidden)
+        dln2 = torch.empty(M, Dp, dtype=torch.bfloat16, device=x.device)
+        ops.gemm(du, sh["fc1_w"], dln2, M, Dp, dm.Hp, dm.Hp, Dp, Dp, b_layout=1)
+        del du
+        dx1, dx1b, d_n2w, d_n2b = ops.layernorm_bwd(dln2, Dp, x1, Dp, n2w, mean2, rstd2, M, D, Dp, dx_in=dx2,
+                                                    want_bf16=True, ld_dxb=Dp)
+        # ---- attention
+        d_projw = wgrad(dx1b, Dp, o, dm.AO, D, D, M, col_seg=(dm.hdp, dm.hd), n_phys=dm.AO)
+        d_projb = ops.colsum(dx1b, Dp, M, D)
+        do = torch.empty(M, dm.AO, dtype=torch.bfloat16, device=x.device)
+        ops.gemm(dx1b, sh["proj_w"], do, M, dm.AO, Dp, Dp, dm.AO, dm.AO, b_layout=1)
+        dqkv = attention_bwd(do, qkv, o, ctx.att_saved, B, N, dm)
+        d_qkvw = wgrad(dqkv, dm.QKV, ln1, Dp, 3 * D, D, M, row_seg=(dm.hdp, dm.hd), m_phys=dm.QKV)
+        d_qkvb = None
+        if blk.attn.qkv.bias is not None:
+            d_qkvb = ops.unpack_vec(ops.colsum(dqkv, dm.QKV, M, dm.QKV), 3 * D, seg=(dm.hdp, dm.hd))
+        dln1 = torch.empty(M, Dp, dtype=torch.bfloat16, device=x.device)
+        ops.gemm(dqkv, sh["qkv_w"], dln1, M, Dp, dm.QKV, dm.QKV, Dp, Dp, b_layout=1)
+        dx, _, d_n1w, d_n1b = ops.layernorm_bwd(dln1, Dp, x, Dp, n1w, mean1, rstd1, M, D, Dp, dx_in=dx1)
+        return (dx.view(B, N, Dp), None, d_n1w, d_n1b, d_qkvw, d_qkvb, d_projw, d_projb, d_n2w, d_n2b, d_fc1w, d_fc1b,
+                d_fc2w, d_fc2b)
+
+
+class Block(nn.Module):
+    """Drop-in for ``timm.models.vision_transformer.Block`` (0.6.12): same constructor, attribute and
+    state_dict key names (norm1, attn.qkv, attn.proj, norm2, mlp.fc1, mlp.fc2).  Only the configuration
+    the reference uses is implemented (no dropout / layer-scale / drop-path, exact-erf GELU, LayerNorm)."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, drop=0., attn_drop=0., init_values=None,
+                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        if drop or attn_drop or drop_path or init_values is not None:
+            raise NotImplementedError("vita_amd.Block: dropout / layer-scale / drop-path are not used by ViTa")
+        if act_layer is not nn.GELU or norm_layer is not nn.LayerNorm:
+            raise NotImplementedError("vita_amd.Block: only nn.GELU + nn.LayerNorm (the reference configuration)")
+        hidden = int(dim * mlp_ratio)
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads, qkv_bias)
+        self.ls1 = nn.Identity(); self.drop_path1 = nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(dim, hidden)
+        self.ls2 = nn.Identity(); self.drop_path2 = nn.Identity()
+        self.dims = Dims(dim, num_heads, hidden)
+        self.use_flash = False
+        self._sh = _Shadows()
+
+    def shadows(self):
+        dm, g = self.dims, self._sh.get
+        seg = (dm.hdp, dm.hd)
+        a, m = self.attn, self.mlp
+        dev = a.proj.weight.device
+        zeros = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)
+        return {
+            "qkv_w": g("qkv_w", a.qkv.weight, lambda p: ops.pack_weight(p, dm.QKV, dm.Dp, row_seg=seg)),
+            "qkv_b": g("qkv_b", a.qkv.bias, lambda p: ops.pack_vec(p, dm.QKV, seg=seg)) if a.qkv.bias is not None
+            else g("qkv_b0", a.qkv.weight, lambda p: zeros(dm.QKV)),
+            "proj_w": g("proj_w", a.proj.weight, lambda p: ops.pack_weight(p, dm.Dp, dm.AO, col_seg=seg)),
+            "proj_b": g("proj_b", a.proj.bias, lambda p: ops.pack_vec(p, dm.Dp)),
+            "fc1_w": g("fc1_w", m.fc1.weight, lambda p: ops.pack_weight(p, dm.Hp, dm.Dp)),
+            "fc1_b": g("fc1_b", m.fc1.bias, lambda p: ops.pack_vec(p, dm.Hp)),
+            "fc2_w": g("fc2_w", m.fc2.weight, lambda p: ops.pack_weight(p, dm.Dp, dm.Hp)),
+            "fc2_b": g("fc2_b", m.fc2.bias, lambda p: ops.pack_vec(p, dm.Dp)),
+        }
+
+    def forward_padded(self, xp: torch.Tensor) -> torch.Tensor:
+        """xp fp32 [B,N,Dp] contiguous with zero pads -> same layout."""
+        a, m = self.attn, self.mlp
+        return _BlockFn.apply(xp, self, self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight,
+                              a.proj.bias, self.norm2.weight, self.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight,
+                              m.fc2.bias)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _require_cuda(x)
+        D = self.dims.D
+        return self.forward_padded(pad_tokens(x.float(), self.dims.Dp))[..., :D]
+
+
+def _require_cuda(x):
+    if not x.is_cuda:
+        raise RuntimeError("vita_amd modules run only on an MI355X (cuda device); there is no CPU fallback")
+
+
+# ----------------------------------------------------------------------------- LayerNorm / Linear on the padded stream
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xp, w, b, eps, D):
+        B, N, Dp = xp.shape
+        x = xp.reshape(B * N, Dp)
+        y, mean, rstd = ops.layernorm_fwd(x, Dp, w, b, B * N, D, Dp, out_dtype=torch.float32, eps=eps)
+        ctx.save_for_backward(x, w, mean, rstd)
+        ctx.D = D
+        return y.view(B, N, Dp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        B, N, Dp = dy.shape
+        dy = dy.contiguous().view(B * N, Dp)
+        dx, _, dw, db = ops.layernorm_bwd(dy, Dp, x, Dp, w, mean, rstd, B * N, ctx.D, Dp)
+        return dx.view(B, N, Dp), dw, db, None, None
+
+
+def layer_norm_padded(xp, ln: nn.LayerNorm):
+    return _LayerNormFn.apply(xp, ln.weight, ln.bias, ln.eps, ln.normalized_shape[0])
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b on the padded fp32 stream: [B,N,Kp] -> [B,N,Np] (bf16 MFMA, fp32 out)."""
+
+    @staticmethod
+    def forward(ctx, xp, w, b, holder, Np):
+        B, N, Kp = xp.shape
+        M = B * N
+        out_f, in_f = w.shape
+        ws = holder.get("w", w, lambda p: ops.pack_weight(p, Np, Kp))
+        bs = holder.get("b", b, lambda p: ops.pack_vec(p, Np))
+        xb = ops.cast_bf16(xp.reshape(M, Kp), Kp, M, in_f, Kp)
+        y = torch.empty(M, Np, dtype=torch.float32, device=xp.device)
+        ops.gemm(xb, ws, y, M, Np, Kp, Kp, Kp, Np, bias=bs)
+        ctx.save_for_backward(xb, ws)
+        ctx.dims = (B, N, Kp, Np, out_f, in_f)
+        return y.view(B, N, Np)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xb, ws = ctx.saved_tensors
+        B, N, Kp, Np, out_f, in_f = ctx.dims
+        M = B * N
+        dy = dy.contiguous().view(M, Np)
+        dyb = ops.cast_bf16(dy, Np, M, out_f, Np)
+        dw = wgrad(dyb, Np, xb, Kp, out_f, in_f, M)
+        db = ops.colsum(dyb, Np, M, out_f)
+        dx = torch.empty(M, Kp, dtype=torch.float32, device=dy.device)
+        ops.gemm(dyb, ws, dx, M, Kp, Np, Np, Kp, Kp, b_layout=1)
+        return dx.view(B, N, Kp), dw, db, None, None
+
+
+def linear_padded(xp, lin: nn.Linear, holder: _Shadows, Np: int):
+    return _LinearFn.apply(xp, lin.weight, lin.bias, holder, Np)

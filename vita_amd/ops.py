@@ -119,9 +119,9 @@ def argsort_mask(noise: torch.Tensor, len_keep: int):
     return ids_shuffle, ids_restore, mask
 
 
-def row_gather(x, ldx, l_in, ids, ld_ids, l_out, nb, d, ldo, fill=None):
+def row_gather(x, ldx, l_in, ids, ld_ids, l_out, nb, d, ldo, fill=None, pos=None):
     out = torch.empty(nb, l_out, ldo, dtype=torch.float32, device=x.device)
-    check(_lib.lib().vita_row_gather_f32(x.data_ptr(), ldx, l_in, ids.data_ptr(), ld_ids, _p(fill), out.data_ptr(), ldo,
+    check(_lib.lib().vita_row_gather_f32(x.data_ptr(), ldx, l_in, ids.data_ptr(), ld_ids, _p(fill), _p(pos), out.data_ptr(), ldo,
                                          l_out, nb, d, _s()), "row_gather")
     return out
 
@@ -134,19 +134,32 @@ def row_scatter(dout, ldo, l_out, ids, ld_ids, l_in, nb, d, ldx, want_dfill=Fals
     return dx, dfill
 
 
-def im2col(img, patch, ids, n_tok, ldo):
+def im2col(img, patch, ids, n_tok, ldo, with_cls_row=False):
+    """bf16 patch matrix; with_cls_row: layout [nb][1+n_tok][ldo] with a zero row 0 per batch."""
     nb, S, T, H, W = img.shape
     assert img.dtype == torch.float32 and img.is_contiguous()
-    out = torch.empty(nb * n_tok, ldo, dtype=torch.bfloat16, device=img.device)
+    if with_cls_row:
+        out = torch.zeros(nb * (n_tok + 1), ldo, dtype=torch.bfloat16, device=img.device)
+        bro, r0 = n_tok + 1, 1
+    else:
+        out = torch.empty(nb * n_tok, ldo, dtype=torch.bfloat16, device=img.device)
+        bro, r0 = n_tok, 0
     check(_lib.lib().vita_im2col_bf16(img.data_ptr(), nb, S, T, H, W, patch[0], patch[1], patch[2], _p(ids), n_tok,
-                                      out.data_ptr(), ldo, _s()), "im2col")
+                                      out.data_ptr(), ldo, bro, r0, _s()), "im2col")
     return out
 
 
-def tokens_assemble(y, ldy, cls, pos, ids, nb, n_tok, d, ldo):
+def tokens_assemble(y, ldy, cls, pos, ids, nb, n_tok, d, ldo, inplace_with_cls_row=False):
+    """inplace_with_cls_row: y is [nb][1+n_tok][ldy] (row 0 = scratch) and is finished in place."""
+    if inplace_with_cls_row:
+        assert ldy == ldo
+        out = y.view(nb, n_tok + 1, ldo)
+        check(_lib.lib().vita_tokens_assemble(y.data_ptr() + 4 * ldy, ldy, cls.data_ptr(), _p(pos), _p(ids), nb, n_tok, d,
+                                              out.data_ptr(), ldo, n_tok + 1, _s()), "tokens_assemble")
+        return out
     out = torch.empty(nb, n_tok + 1, ldo, dtype=torch.float32, device=y.device)
     check(_lib.lib().vita_tokens_assemble(y.data_ptr(), ldy, cls.data_ptr(), _p(pos), _p(ids), nb, n_tok, d,
-                                          out.data_ptr(), ldo, _s()), "tokens_assemble")
+                                          out.data_ptr(), ldo, n_tok, _s()), "tokens_assemble")
     return out
 
 

@@ -1,0 +1,139 @@
+"""Step driver for the hot path: Stage-I model (encoder + decoder + fused loss) mirroring
+models/reconstruction_models.py:105-134 without the Lightning harness, a flat-buffer Adam
+(models/reconstruction_models.py:36-38) and a bucketed RCCL gradient all-reduce overlapped with
+backward (the explicit counterpart of Lightning's strategy="ddp", main.py:61)."""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from . import ops
+from .losses import recon_mse_from_logits
+from .networks import ImagingMaskedDecoder, ImagingMaskedEncoder
+from .nn import bump_shadow_epoch
+
+
+class ReconMAE(nn.Module):
+    """encoder_imaging + decoder_imaging with the reference's state_dict key prefixes."""
+
+    def __init__(self, img_shape, use_both_axes=True, **hparams):
+        super().__init__()
+        self.hparams_ = dict(hparams)
+        self.patch_size = hparams["patch_size"]
+        self.mask_loss = bool(hparams.get("mask_loss", False))
+        self.encoder_imaging = ImagingMaskedEncoder(img_shape=img_shape, use_both_axes=use_both_axes, **hparams)
+        self.decoder_imaging = ImagingMaskedDecoder(num_patches=self.encoder_imaging.patch_embed.num_patches,
+                                                    grid_size=self.encoder_imaging.patch_embed.grid_size,
+                                                    use_both_axes=use_both_axes,
+                                                    head_out_dim=self.encoder_imaging.patch_p_num, **hparams)
+
+    def forward(self, x):
+        x, mask, ids_restore = self.encoder_imaging(x)
+        x = self.decoder_imaging(x, ids_restore)
+        return x, mask
+
+    def training_loss(self, imgs, want_pred=False):
+        """models/reconstruction_models.py:128-134: forward, patchify target, MSE (fused)."""
+        xp, mask, ids_restore = self.encoder_imaging.forward_padded(imgs)
+        D = self.encoder_imaging.enc_embed_dim
+        z = self.decoder_imaging.forward_logits_padded(xp[..., :D], ids_restore)
+        loss, pred = recon_mse_from_logits(z, imgs, self.patch_size, int(self.encoder_imaging.patch_p_num), mask,
+                                           self.mask_loss, want_pred)
+        return loss, pred, mask
+
+
+class FlatAdam:
+    """torch.optim.Adam semantics on one flat fp32 buffer (params and grads become views of it)."""
+
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.params = [p for p in params if p.requires_grad]
+        dev = self.params[0].device
+        sizes = [ops.rup(p.numel(), 4) for p in self.params]
+        self.offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        n = int(self.offsets[-1])
+        self.p = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.offsets[:-1]):
+            view = self.p[o:o + p.numel()].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.g[o:o + p.numel()].view(p.shape)
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.t = 0
+        bump_shadow_epoch()
+
+    def zero_grad(self):
+        self.g.zero_()
+
+    def step(self, grad_scale=1.0, lr=None):
+        self.t += 1
+        ops.adam_step(self.p, self.g, self.m, self.v, self.lr if lr is None else lr, self.betas[0], self.betas[1],
+                      self.eps, self.wd, grad_scale, self.t)
+        bump_shadow_epoch()
+
+
+class BucketedAllReduce:
+    """Gradient all-reduce over RCCL in ~bucket_mb buckets of the flat gradient buffer, launched from
+    post-accumulate hooks as soon as every parameter of a bucket has its gradient (reverse order =
+    backward order), on a side stream so it overlaps the rest of backward."""
+
+    def __init__(self, opt: FlatAdam, group=None, bucket_mb=48):
+        self.opt, self.group = opt, group
+        self.world = dist.get_world_size(group)
+        self.stream = torch.cuda.Stream()
+        cap = bucket_mb * (1 << 20) // 4
+        self.buckets = []           # (start, end, n_params)
+        self.bucket_of = {}
+        end = int(opt.offsets[-1]); cnt = 0; hi = end
+        for i in range(len(opt.params) - 1, -1, -1):
+            lo = int(opt.offsets[i]); cnt += 1
+            self.bucket_of[i] = len(self.buckets)
+            if hi - lo >= cap or i == 0:
+                self.buckets.append((lo, hi, cnt)); hi = lo; cnt = 0
+        self.pending = [0] * len(self.buckets)
+        self.handles = []
+        for i, p in enumerate(opt.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i):
+        def hook(_p):
+            b = self.bucket_of[i]
+            self.pending[b] += 1
+            if self.pending[b] == self.buckets[b][2]:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        lo, hi, _ = self.buckets[b]
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            self.handles.append(dist.all_reduce(self.opt.g[lo:hi], group=self.group, async_op=True))
+
+    def finish(self):
+        """Wait for every bucket (launching any whose hooks did not all fire) and reset."""
+        for b, n in enumerate(self.pending):
+            if n != self.buckets[b][2]:
+                self._launch(b)
+        for h in self.handles:
+            h.wait()
+        torch.cuda.current_stream().wait_stream(self.stream)
+        self.handles = []
+        self.pending = [0] * len(self.buckets)
+
+
+def stage1_train_step(model: ReconMAE, opt: FlatAdam, imgs, reducer: Optional[BucketedAllReduce] = None):
+    opt.zero_grad()
+    loss, _, _ = model.training_loss(imgs)
+    loss.backward()
+    if reducer is not None:
+        reducer.finish()
+        opt.step(grad_scale=1.0 / reducer.world)
+    else:
+        opt.step()
+    return loss
