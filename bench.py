@@ -1,0 +1,170 @@
+"""Benchmark of the ViTa Stage-I MAE train step (BASELINE.json configs[1]) on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W [--frames T] [--batch B]
+
+A step = forward + backward + gradient all-reduce (N>1) + Adam over one batch of synthetic
+SAX+LAX cine stacks already resident in HBM.  One JSON line is printed by rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+REF_CFG = dict(  # configs/imaging_model/pretraining_reconstruction_mae.yaml + configs/imaging_params.py defaults
+    patch_size=(5, 8, 8), enc_embed_dim=1025, enc_depth=6, enc_num_heads=5, dec_embed_dim=1025, dec_depth=2,
+    dec_num_heads=5, mlp_ratio=4.0, mask_ratio=0.7, mask_type="random", use_enc_pe=True, circular_pe=False,
+    patch_embed_cls="PatchEmbed", patch_in_channels=1, mask_loss=False, grad_checkpointing=False)
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def blk_flops(n, d):
+    """one Block forward per sample."""
+    return 24.0 * n * d * d + 4.0 * n * n * d
+
+
+def step_flops_per_subject(T, cfg=REF_CFG, S=9, HW=128):
+    L = S * (T // cfg["patch_size"][0]) * (HW // cfg["patch_size"][1]) * (HW // cfg["patch_size"][2])
+    keep = int(L * (1 - cfg["mask_ratio"]))
+    D, Dd, P = cfg["enc_embed_dim"], cfg["dec_embed_dim"], 320
+    fwd = 2.0 * keep * P * D + cfg["enc_depth"] * blk_flops(keep + 1, D) + 2.0 * (keep + 1) * D * Dd \
+        + cfg["dec_depth"] * blk_flops(L + 1, Dd) + 2.0 * (L + 1) * Dd * P
+    return 3.0 * fwd, L, keep
+
+
+def cpu_baseline(frames, steps=2):
+    """Oracle (CPU restatement of the reference path, fp32 torch CPU ops) on a bounded sample:
+    the full-size model on ONE subject with `frames` frames; reported extrapolated to the bench
+    workload through the algorithmic FLOP count."""
+    from oracle import vita_oracle as O
+    import numpy as np
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    img = (9, frames, 128, 128)
+    p = O.init_stage1_params(img_shape=img, patch_size=REF_CFG["patch_size"], enc_dim=1025, enc_depth=6, enc_heads=5,
+                             dec_dim=1025, dec_depth=2, dec_heads=5, seed=1)
+    g = torch.Generator().manual_seed(1)
+    imgs = torch.rand(1, *img, generator=g)
+    L = 9 * (frames // 5) * 16 * 16
+    cfg = dict(patch_size=REF_CFG["patch_size"], enc_depth=6, enc_heads=5, dec_depth=2, dec_heads=5, mask_ratio=0.7)
+    state = {}
+    times = []
+    for i in range(steps + 1):
+        noise = np.random.RandomState(i).rand(1, L).astype(np.float32)
+        t0 = time.perf_counter()
+        O.stage1_train_step(imgs, p, noise, state, lr=1e-4, **cfg)
+        times.append(time.perf_counter() - t0)
+    dt = sum(times[1:]) / steps
+    fl, _, _ = step_flops_per_subject(frames)
+    return dt, fl / dt / 1e12, cores
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=50, help="T: 50 = BASELINE.json shape, 25 = shipped yaml")
+    ap.add_argument("--batch", type=int, default=2, help="subjects per GPU (reference yaml: 2)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=5)
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--materialized-attention", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from vita_amd import nn as vnn, ops
+    from vita_amd.train import BucketedAllReduce, FlatAdam, ReconMAE, stage1_train_step
+    if args.materialized_attention:
+        vnn.DEFAULT_FLASH = False
+
+    T, B = args.frames, args.batch
+    img_shape = [9, T, 128, 128]
+    torch.manual_seed(1)                      # reference seed (yaml general.seed / main.py:22), same on every rank
+    model = ReconMAE(img_shape=img_shape, use_both_axes=True, **REF_CFG).cuda()
+    opt = FlatAdam(model.parameters(), lr=1e-4)
+    reducer = BucketedAllReduce(opt) if world > 1 else None
+    gen = torch.Generator(device="cuda").manual_seed(1 + rank)
+    imgs = torch.rand(B, *img_shape, device="cuda", generator=gen)
+
+    for _ in range(args.warmup):
+        stage1_train_step(model, opt, imgs, reducer)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not args.no_kernel_timing:
+        ops.PROF = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = stage1_train_step(model, opt, imgs, reducer)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof, ops.PROF = ops.PROF, None
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    if rank == 0:
+        step_fl, L, keep = step_flops_per_subject(T)
+        ms = dt / args.steps * 1e3
+        value = world * B * args.steps / dt
+        out = {
+            "metric": "CMR subjects/sec per train step (Stage I MAE)", "value": round(value, 4), "unit": "subjects/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Stage I MAE train step (fwd+bwd+Adam), D=1025 enc6/dec2 heads5 mask0.7, "
+                                   f"9x{T}x128x128 SAX+LAX, patch 5x8x8 (L={L}, keep={keep})",
+                       "per_gpu_batch": B, "global_batch": world * B, "frames": T,
+                       "parallelism": f"dp{world}", "loss": round(float(loss.detach()), 6)},
+            "step_tflop_per_subject": round(step_fl / 1e12, 3),
+            "model_tflops_per_gpu": round(step_fl * B * args.steps / dt / 1e12, 1),
+        }
+        if prof:
+            agg = {}
+            for name, e0, e1, work in prof:
+                a = agg.setdefault(name, [0.0, 0.0, 0])
+                a[0] += e0.elapsed_time(e1) * 1e-3; a[1] += work; a[2] += 1
+            dom = max(agg, key=lambda k: agg[k][0])
+            tsec, work, cnt = agg[dom]
+            out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(work / tsec / 1e12, 1),
+                               "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(work / tsec / 1e12 / PEAK_BF16_TFLOPS, 4),
+                               "traffic": None, "launches_per_step": cnt // args.steps,
+                               "avg_launch_ms": round(tsec / cnt * 1e3, 4),
+                               "algorithmic_gflop_per_launch": round(work / cnt / 1e9, 2)}
+            out["kernels"] = {k: {"ms_per_step": round(v[0] / args.steps * 1e3, 3),
+                                  "tflops": round(v[1] / v[0] / 1e12, 1), "launches_per_step": v[2] // args.steps}
+                              for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
+        if world == 1 and not args.no_cpu_baseline:
+            cdt, ctf, cores = cpu_baseline(args.cpu_frames)
+            out["cpu_baseline"] = {"value": round(ctf * 1e12 / step_fl, 6), "unit": "subjects/s", "cores": cores, "kind": "port",
+                                   "sample": f"oracle Stage-I train step, full model (D=1025 enc6/dec2), 1 subject x {args.cpu_frames} frames, "
+                                             f"fp32 torch CPU, {cdt:.2f} s/step = {ctf:.3f} TFLOP/s algorithmic; value = that rate / "
+                                             f"{step_fl / 1e12:.2f} TFLOP per subject at {T} frames"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

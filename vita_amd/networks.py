@@ -88,7 +88,7 @@ class _TokenizeFn(torch.autograd.Function):
         cols = ops.im2col(img, patch, ids, n, Pp, with_cls_row=with_cls)
         rows = cols.shape[0]
         y = torch.empty(rows, Dp, dtype=torch.float32, device=img.device)
-        ops.gemm(cols, ws, y, rows, Dp, Pp, Pp, Pp, Dp, bias=bs)
+        ops.gemm(cols, ws, y, rows, Dp, Pp, Pp, Pp, Dp, bias=bs, flops=2.0 * B * n * D * P)
         if with_cls:
             posl = pos.reshape(-1, D) if pos is not None else None
             out = ops.tokens_assemble(y, Dp, cls.reshape(-1), posl, ids, B, n, D, Dp, inplace_with_cls_row=True)

@@ -20,6 +20,7 @@ from torch import nn
 from . import ops
 
 _SHADOW_EPOCH = 0
+DEFAULT_FLASH = False   # flipped to True once the fused attention kernels are built
 
 
 def bump_shadow_epoch():
@@ -98,12 +99,12 @@ def attention_fwd(qkv, B, N, dm: Dims, use_flash: bool):
     Nld = ops.rup(N, 8)
     s = torch.empty(B, H, N, Nld, dtype=torch.float32, device=dev)
     ops.gemm(qkv, qkv, s, N, N, hdp, QKV, QKV, Nld, batch=(B, H), a_strides=(N * QKV, hdp),
-             b_strides=(N * QKV, hdp), c_strides=(H * N * Nld, N * Nld), b_off=AO)
+             b_strides=(N * QKV, hdp), c_strides=(H * N * Nld, N * Nld), b_off=AO, flops=2.0 * B * H * N * N * dm.hd)
     p = torch.empty(B, H, N, Nld, dtype=torch.bfloat16, device=dev)
     ops.softmax_rows(s, Nld, p, Nld, B * H * N, N, dm.scale)
     del s
     ops.gemm(p, qkv, o, N, hdp, N, Nld, QKV, AO, b_layout=1, batch=(B, H), a_strides=(H * N * Nld, N * Nld),
-             b_strides=(N * QKV, hdp), c_strides=(N * AO, hdp), b_off=2 * AO)
+             b_strides=(N * QKV, hdp), c_strides=(N * AO, hdp), b_off=2 * AO, flops=2.0 * B * H * N * N * dm.hd)
     return o, ("mat", p)
 
 
@@ -118,21 +119,22 @@ def attention_bwd(do, qkv, o, saved, B, N, dm: Dims):
     p = saved[1]
     Nld = p.shape[-1]
     bs_qkv, bs_p, bs_o = (N * QKV, hdp), (H * N * Nld, N * Nld), (N * AO, hdp)
+    fl = 2.0 * B * H * N * N * dm.hd
     dp = torch.empty(B, H, N, Nld, dtype=torch.float32, device=dev)
     # dP = dO V^T
     ops.gemm(do, qkv, dp, N, N, hdp, AO, QKV, Nld, batch=(B, H), a_strides=bs_o, b_strides=bs_qkv, c_strides=bs_p,
-             b_off=2 * AO)
+             b_off=2 * AO, flops=fl)
     # dV = P^T dO
     ops.gemm(p, do, dqkv, N, hdp, N, Nld, AO, QKV, a_layout=1, b_layout=1, batch=(B, H), a_strides=bs_p,
-             b_strides=bs_o, c_strides=bs_qkv, c_off=2 * AO)
+             b_strides=bs_o, c_strides=bs_qkv, c_off=2 * AO, flops=fl)
     ds = torch.empty(B, H, N, Nld, dtype=torch.bfloat16, device=dev)
     ops.softmax_bwd_rows(p, Nld, dp, Nld, ds, Nld, B * H * N, N, dm.scale)
     del dp
     # dQ = dS K ; dK = dS^T Q
     ops.gemm(ds, qkv, dqkv, N, hdp, N, Nld, QKV, QKV, b_layout=1, batch=(B, H), a_strides=bs_p, b_strides=bs_qkv,
-             c_strides=bs_qkv, b_off=AO)
+             c_strides=bs_qkv, b_off=AO, flops=fl)
     ops.gemm(ds, qkv, dqkv, N, hdp, N, Nld, QKV, QKV, a_layout=1, b_layout=1, batch=(B, H), a_strides=bs_p,
-             b_strides=bs_qkv, c_strides=bs_qkv, c_off=AO)
+             b_strides=bs_qkv, c_strides=bs_qkv, c_off=AO, flops=fl)
     return dqkv
 
 
@@ -150,7 +152,7 @@ def wgrad(dy, lddy, x, ldx, rows_out, cols_out, k_tokens, row_seg=(0, 0), col_se
     sk = _split_k_for(m, n, k_tokens)
     out = (torch.zeros if sk > 1 else torch.empty)(rows_out, cols_out, dtype=torch.float32, device=dy.device)
     ops.gemm(dy, x, out, m, n, k_tokens, lddy, ldx, cols_out, a_layout=1, b_layout=1, split_k=sk,
-             row_seg=row_seg, col_seg=col_seg)
+             row_seg=row_seg, col_seg=col_seg, flops=2.0 * rows_out * cols_out * k_tokens)
     return out
 
 
@@ -165,18 +167,19 @@ class _BlockFn(torch.autograd.Function):
         x = xp.reshape(M, Dp)
         ln1, mean1, rstd1 = ops.layernorm_fwd(x, Dp, n1w, n1b, M, dm.D, Dp, eps=blk.norm1.eps)
         qkv = torch.empty(M, dm.QKV, dtype=torch.bfloat16, device=x.device)
-        ops.gemm(ln1, sh["qkv_w"], qkv, M, dm.QKV, Dp, Dp, Dp, dm.QKV, bias=sh["qkv_b"])
-        o, att_saved = attention_fwd(qkv, B, N, dm, blk.use_flash)
+        ops.gemm(ln1, sh["qkv_w"], qkv, M, dm.QKV, Dp, Dp, Dp, dm.QKV, bias=sh["qkv_b"], flops=6.0 * M * dm.D * dm.D)
+        o, att_saved = attention_fwd(qkv, B, N, dm, DEFAULT_FLASH if blk.use_flash is None else blk.use_flash)
         x1 = torch.empty(M, Dp, dtype=torch.float32, device=x.device)
         ops.gemm(o, sh["proj_w"], x1, M, Dp, dm.AO, dm.AO, dm.AO, Dp, bias=sh["proj_b"], epilogue=ops.EPI_RESIDUAL,
-                 aux_in=x, ld_aux=Dp)
+                 aux_in=x, ld_aux=Dp, flops=2.0 * M * dm.D * dm.D)
         ln2, mean2, rstd2 = ops.layernorm_fwd(x1, Dp, n2w, n2b, M, dm.D, Dp, eps=blk.norm2.eps)
         u = torch.empty(M, dm.Hp, dtype=torch.bfloat16, device=x.device)
         g = torch.empty(M, dm.Hp, dtype=torch.bfloat16, device=x.device)
-        ops.gemm(ln2, sh["fc1_w"], g, M, dm.Hp, Dp, Dp, Dp, dm.Hp, bias=sh["fc1_b"], epilogue=ops.EPI_GELU, aux_out=u)
+        ops.gemm(ln2, sh["fc1_w"], g, M, dm.Hp, Dp, Dp, Dp, dm.Hp, bias=sh["fc1_b"], epilogue=ops.EPI_GELU, aux_out=u,
+                 flops=2.0 * M * dm.D * dm.hidden)
         x2 = torch.empty(M, Dp, dtype=torch.float32, device=x.device)
         ops.gemm(g, sh["fc2_w"], x2, M, Dp, dm.Hp, dm.Hp, dm.Hp, Dp, bias=sh["fc2_b"], epilogue=ops.EPI_RESIDUAL,
-                 aux_in=x1, ld_aux=Dp)
+                 aux_in=x1, ld_aux=Dp, flops=2.0 * M * dm.D * dm.hidden)
         ctx.blk = blk
         ctx.shape = (B, N)
         ctx.att_saved = att_saved
@@ -198,11 +201,11 @@ class _BlockFn(torch.autograd.Function):
         d_fc2b = ops.colsum(dyb, Dp, M, D)
         du = torch.empty(M, dm.Hp, dtype=torch.bfloat16, device=x.device)
         ops.gemm(dyb, sh["fc2_w"], du, M, dm.Hp, Dp, Dp, dm.Hp, dm.Hp, b_layout=1, epilogue=ops.EPI_GELU_BWD, aux_in=u,
-                 ld_aux=dm.Hp)
+                 ld_aux=dm.Hp, flops=2.0 * M * D * dm.hidden)
         d_fc1w = wgrad(du, dm.Hp, ln2, Dp, dm.hidden, D, M)
         d_fc1b = ops.colsum(du, dm.Hp, M, dm.hidden)
         dln2 = torch.empty(M, Dp, dtype=torch.bfloat16, device=x.device)
-        ops.gemm(du, sh["fc1_w"], dln2, M, Dp, dm.Hp, dm.Hp, Dp, Dp, b_layout=1)
+        ops.gemm(du, sh["fc1_w"], dln2, M, Dp, dm.Hp, dm.Hp, Dp, Dp, b_layout=1, flops=2.0 * M * D * dm.hidden)
         del du
         dx1, dx1b, d_n2w, d_n2b = ops.layernorm_bwd(dln2, Dp, x1, Dp, n2w, mean2, rstd2, M, D, Dp, dx_in=dx2,
                                                     want_bf16=True, ld_dxb=Dp)
@@ -210,14 +213,14 @@ class _BlockFn(torch.autograd.Function):
         d_projw = wgrad(dx1b, Dp, o, dm.AO, D, D, M, col_seg=(dm.hdp, dm.hd), n_phys=dm.AO)
         d_projb = ops.colsum(dx1b, Dp, M, D)
         do = torch.empty(M, dm.AO, dtype=torch.bfloat16, device=x.device)
-        ops.gemm(dx1b, sh["proj_w"], do, M, dm.AO, Dp, Dp, dm.AO, dm.AO, b_layout=1)
+        ops.gemm(dx1b, sh["proj_w"], do, M, dm.AO, Dp, Dp, dm.AO, dm.AO, b_layout=1, flops=2.0 * M * D * D)
         dqkv = attention_bwd(do, qkv, o, ctx.att_saved, B, N, dm)
         d_qkvw = wgrad(dqkv, dm.QKV, ln1, Dp, 3 * D, D, M, row_seg=(dm.hdp, dm.hd), m_phys=dm.QKV)
         d_qkvb = None
         if blk.attn.qkv.bias is not None:
             d_qkvb = ops.unpack_vec(ops.colsum(dqkv, dm.QKV, M, dm.QKV), 3 * D, seg=(dm.hdp, dm.hd))
         dln1 = torch.empty(M, Dp, dtype=torch.bfloat16, device=x.device)
-        ops.gemm(dqkv, sh["qkv_w"], dln1, M, Dp, dm.QKV, dm.QKV, Dp, Dp, b_layout=1)
+        ops.gemm(dqkv, sh["qkv_w"], dln1, M, Dp, dm.QKV, dm.QKV, Dp, Dp, b_layout=1, flops=6.0 * M * D * D)
         dx, _, d_n1w, d_n1b = ops.layernorm_bwd(dln1, Dp, x, Dp, n1w, mean1, rstd1, M, D, Dp, dx_in=dx1)
         return (dx.view(B, N, Dp), None, d_n1w, d_n1b, d_qkvw, d_qkvb, d_projw, d_projb, d_n2w, d_n2b, d_fc1w, d_fc1b,
                 d_fc2w, d_fc2b)
@@ -243,7 +246,7 @@ class Block(nn.Module):
         self.mlp = Mlp(dim, hidden)
         self.ls2 = nn.Identity(); self.drop_path2 = nn.Identity()
         self.dims = Dims(dim, num_heads, hidden)
-        self.use_flash = False
+        self.use_flash = None   # None -> module default (DEFAULT_FLASH)
         self._sh = _Shadows()
 
     def shadows(self):
@@ -318,7 +321,7 @@ class _LinearFn(torch.autograd.Function):
         bs = holder.get("b", b, lambda p: ops.pack_vec(p, Np))
         xb = ops.cast_bf16(xp.reshape(M, Kp), Kp, M, in_f, Kp)
         y = torch.empty(M, Np, dtype=torch.float32, device=xp.device)
-        ops.gemm(xb, ws, y, M, Np, Kp, Kp, Kp, Np, bias=bs)
+        ops.gemm(xb, ws, y, M, Np, Kp, Kp, Kp, Np, bias=bs, flops=2.0 * M * out_f * in_f)
         ctx.save_for_backward(xb, ws)
         ctx.dims = (B, N, Kp, Np, out_f, in_f)
         return y.view(B, N, Np)
@@ -333,7 +336,7 @@ class _LinearFn(torch.autograd.Function):
         dw = wgrad(dyb, Np, xb, Kp, out_f, in_f, M)
         db = ops.colsum(dyb, Np, M, out_f)
         dx = torch.empty(M, Kp, dtype=torch.float32, device=dy.device)
-        ops.gemm(dyb, ws, dx, M, Kp, Np, Np, Kp, Kp, b_layout=1)
+        ops.gemm(dyb, ws, dx, M, Kp, Np, Np, Kp, Kp, b_layout=1, flops=2.0 * M * out_f * in_f)
         return dx.view(B, N, Kp), dw, db, None, None
 
 

@@ -34,11 +34,30 @@ def _dt(t: torch.Tensor) -> int:
     raise TypeError(f"unsupported dtype {t.dtype}")
 
 
+# Optional per-launch timing for bench.py: PROF = [] enables (name, start_event, end_event, algorithmic_work).
+PROF = None
+
+
+class _Timed:
+    def __init__(self, name, work):
+        self.name, self.work = name, work
+
+    def __enter__(self):
+        if PROF is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True); self.e0.record()
+
+    def __exit__(self, *exc):
+        if PROF is not None:
+            e1 = torch.cuda.Event(enable_timing=True); e1.record()
+            PROF.append((self.name, self.e0, e1, self.work))
+
+
 def gemm(a, b, c, m, n, k, lda, ldb, ldc, *, a_layout=0, b_layout=0, bias=None, epilogue=EPI_NONE,
          aux_in=None, aux_out=None, ld_aux=0, alpha=1.0, split_k=1, batch=(1, 1),
          a_strides=(0, 0), b_strides=(0, 0), c_strides=(0, 0), row_seg=(0, 0), col_seg=(0, 0),
-         a_off=0, b_off=0, c_off=0):
-    """C[m,n] = epi(alpha * A(m,k) B(k,n)); a/b bf16 tensors, c bf16|fp32.  *_off are element offsets."""
+         a_off=0, b_off=0, c_off=0, flops=None):
+    """C[m,n] = epi(alpha * A(m,k) B(k,n)); a/b bf16 tensors, c bf16|fp32.  *_off are element offsets.
+    flops: algorithmic (un-padded) FLOPs of this launch for the roofline accounting."""
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
     d = GemmDesc()
     d.a = a.data_ptr() + 2 * a_off
@@ -56,7 +75,8 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, *, a_layout=0, b_layout=0, bias=None, 
     d.row_seg_phys, d.row_seg_log = row_seg
     d.col_seg_phys, d.col_seg_log = col_seg
     d.alpha = alpha
-    check(_lib.lib().vita_gemm_bf16(C.byref(d), _s()), "vita_gemm_bf16")
+    with _Timed(f"gemm_kernel<{a_layout},{b_layout}>", flops if flops is not None else 2.0 * m * n * k * batch[0] * batch[1]):
+        check(_lib.lib().vita_gemm_bf16(C.byref(d), _s()), "vita_gemm_bf16")
     return c
 
 
