@@ -162,6 +162,22 @@ int vita_softmax_rows(const float* s, int64_t lds, void* p, int64_t ldp, int64_t
 int vita_softmax_bwd_rows(const void* p, int64_t ldp, const float* dp, int64_t lddp, void* ds,
                           int64_t ldds, int64_t rows, int64_t n, float scale, void* stream);
 
+/* ------------------------------------------------------------------ fused attention
+ * softmax(q k^T * scale) v per (batch, head) without materialising the N x N scores; replaces
+ * timm 0.6.12 Attention.forward's (q @ k^T) * scale -> softmax -> @ v (call sites
+ * networks/imaging_encoders.py:36-40, networks/imaging_decoders.py:43-45).
+ * qkv bf16 [B][N][3][H][hdp] (head dim zero-padded to hdp), o bf16 [B][N][H][hdp], lse fp32 [B][H][N].
+ * vita_attn_supported(hd, hdp) != 0 tells whether a kernel is instantiated for that head size. */
+int vita_attn_supported(int64_t hd, int64_t hdp);
+int vita_attn_fwd(const void* qkv, void* o, float* lse, int64_t B, int64_t N, int64_t H, int64_t hd,
+                  int64_t hdp, float scale, void* stream);
+/* backward: recomputes P from q, k and lse; deterministic (no atomics).  dout bf16 [B][N][H][hdp];
+ * delta fp32 [B][H][N] scratch (rowsum(dout*o), written here); dqkv bf16 like qkv, every element of
+ * the three parts is written (pads zero). */
+int vita_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta,
+                  void* dqkv, int64_t B, int64_t N, int64_t H, int64_t hd, int64_t hdp, float scale,
+                  void* stream);
+
 /* ------------------------------------------------------------------ losses
  * CLIPLoss.forward (utils/clip_loss.py:27-40), kept in fp32:
  *   F.normalize(x, dim=1) (eps 1e-12)           -> vita_l2_normalize_fwd / _bwd

@@ -271,3 +271,54 @@ def test_clip_pieces_and_mse(ops, golden):
     loss.zero_()
     ops.sigmoid_mse_patch(dev(z), 328, dev(x), (5, 8, 8), dev(mask), 1.0 / (mask.sum().item() * P), loss)
     torch.testing.assert_close(loss.cpu()[0], O.reconstruction_mse(torch.sigmoid(zr.detach()), tgt, mask, True), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,N,H,hd", [(2, 197, 5, 205), (1, 64, 3, 43), (2, 333, 2, 128), (1, 1000, 5, 205), (1, 31, 1, 32)])
+def test_flash_attention_fwd(ops, B, N, H, hd):
+    torch.manual_seed(N)
+    hdp = ops.rup(hd, 32)
+    assert ops.attn_supported(hd, hdp)
+    qkv = torch.zeros(B, N, 3, H, hdp)
+    qkv[..., :hd] = torch.randn(B, N, 3, H, hd)
+    qkv[:, 3, 1, 0, :hd] *= 4.0     # one spiky key row: forces a late running-max jump (online-softmax rescale)
+    qb = qkv.to(torch.bfloat16)
+    q, k, v = [qb[:, :, i, :, :hd].float().permute(0, 2, 1, 3) for i in range(3)]
+    scale = hd ** -0.5
+    s = (q @ k.transpose(-1, -2)) * scale
+    ref = torch.softmax(s, -1) @ v
+    lse_ref = torch.logsumexp(s, -1)
+    o = torch.full((B, N, H, hdp), float("nan"), dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B, H, N, device="cuda")
+    ops.attn_fwd(qb.cuda(), o, lse, B, N, H, hd, hdp, scale)
+    oc = o.cpu().float()
+    assert not oc[..., hd:].any()
+    torch.testing.assert_close(oc[..., :hd].permute(0, 2, 1, 3), ref, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(lse.cpu(), lse_ref, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("B,N,H,hd", [(2, 197, 5, 205), (1, 64, 3, 43), (2, 333, 2, 128), (1, 700, 5, 205), (1, 31, 1, 32)])
+def test_flash_attention_bwd(ops, B, N, H, hd):
+    torch.manual_seed(N + 1)
+    hdp = ops.rup(hd, 32)
+    qkv = torch.zeros(B, N, 3, H, hdp)
+    qkv[..., :hd] = torch.randn(B, N, 3, H, hd)
+    qb = qkv.to(torch.bfloat16)
+    do = torch.zeros(B, N, H, hdp); do[..., :hd] = torch.randn(B, N, H, hd)
+    dob = do.to(torch.bfloat16)
+    leaf = qb.float().requires_grad_(True)
+    q, k, v = [leaf[:, :, i, :, :hd].permute(0, 2, 1, 3) for i in range(3)]
+    scale = hd ** -0.5
+    ref = torch.softmax((q @ k.transpose(-1, -2)) * scale, -1) @ v
+    (ref * dob.float()[..., :hd].permute(0, 2, 1, 3)).sum().backward()
+    o = torch.empty(B, N, H, hdp, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B, H, N, device="cuda")
+    qd = qb.cuda()
+    ops.attn_fwd(qd, o, lse, B, N, H, hd, hdp, scale)
+    dqkv = torch.full((B, N, 3, H, hdp), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ops.attn_bwd(qd, o, dob.cuda(), lse, dqkv, B, N, H, hd, hdp, scale)
+    got = dqkv.cpu().float()
+    assert torch.isfinite(got).all() and not got[..., hd:].any()
+    for i, name in enumerate("qkv"):
+        g, r = got[:, :, i, :, :hd], leaf.grad[:, :, i, :, :hd]
+        err = ((g - r).norm() / r.norm()).item()
+        assert err < 2e-2, (name, err)

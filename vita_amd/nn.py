@@ -20,7 +20,7 @@ from torch import nn
 from . import ops
 
 _SHADOW_EPOCH = 0
-DEFAULT_FLASH = False   # flipped to True once the fused attention kernels are built
+DEFAULT_FLASH = True    # fused attention; the materialised path remains for unsupported head sizes and as a cross-check
 
 
 def bump_shadow_epoch():
@@ -92,7 +92,7 @@ def attention_fwd(qkv, B, N, dm: Dims, use_flash: bool):
     dev = qkv.device
     H, hdp, AO, QKV = dm.H, dm.hdp, dm.AO, dm.QKV
     o = torch.empty(B * N, AO, dtype=torch.bfloat16, device=dev)
-    if use_flash:
+    if use_flash and ops.attn_supported(dm.hd, hdp):
         lse = torch.empty(B, H, N, dtype=torch.float32, device=dev)
         ops.attn_fwd(qkv, o, lse, B, N, H, dm.hd, hdp, dm.scale)
         return o, ("flash", lse)

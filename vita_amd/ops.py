@@ -238,3 +238,19 @@ def sigmoid_mse_patch(z, ldz, img, patch, mask, inv_count, loss, pred=None, dz=N
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, grad_scale, step):
     check(_lib.lib().vita_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
                                     weight_decay, grad_scale, step, _s()), "adam_step")
+
+
+def attn_supported(hd, hdp):
+    return bool(_lib.lib().vita_attn_supported(hd, hdp))
+
+
+def attn_fwd(qkv, o, lse, B, N, H, hd, hdp, scale):
+    with _Timed("attn_fwd_kernel", 4.0 * B * H * N * N * hd):
+        check(_lib.lib().vita_attn_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, hd, hdp, scale, _s()), "attn_fwd")
+
+
+def attn_bwd(qkv, o, do, lse, dqkv, B, N, H, hd, hdp, scale):
+    delta = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
+    with _Timed("attn_bwd_kernels", 10.0 * B * H * N * N * hd):
+        check(_lib.lib().vita_attn_bwd(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                       dqkv.data_ptr(), B, N, H, hd, hdp, scale, _s()), "attn_bwd")
