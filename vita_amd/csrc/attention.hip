@@ -1,33 +1,39 @@
 // Fused (flash-style) multi-head attention for gfx950, bf16 MFMA with fp32 online softmax.
-// Replaces the materialised q@k^T -> softmax -> @v of timm 0.6.12 Attention.forward (SURVEY
-// Appendix A; call sites networks/imaging_encoders.py:36-40, networks/imaging_decoders.py:43-45).
+// Replaces the materialised q@k^T -> softmax -> @v of timm 0.6.12 Attention.forward and its autograd
+// backward (call sites networks/imaging_encoders.py:36-40,
+// networks/imaging_decoders.py:43-45).
 //
 // Layout: qkv bf16 [B][N][3][H][HDP] (row stride 3*H*HDP, head dim zero-padded to HDP = 32k),
-//         o   bf16 [B][N][H][HDP], lse fp32 [B][H][N] (natural log).
+//         o / dout bf16 [B][N][H][HDP], lse / delta fp32 [B][H][N] (lse in natural log).
 //
-// Forward: one workgroup = 4 waves = 128 query rows of one (b,h); each wave owns 32 rows.
-//   S^T = K Q^T with v_mfma_f32_32x32x16_bf16 (key on the accumulator rows, query on the lane), so a
-//   lane holds 16 scores of ONE query row: the row max / sum need one cross-half exchange only.
-//   P^T (bf16, straight from the S^T accumulator registers) is the B operand of O^T = V^T P^T;
-//   the V^T fragments come from ds_read_b64_tr_b16 (hardware transpose) of the row-major V tile.
-//   K tile rows are padded by 16 B (odd slot count) -> conflict-free ds_read_b128; V tile rows are
-//   512 B with the 64-B chunk index XOR (row & 3) -> conflict-free transposed reads.
+// Common structure: 4 waves per workgroup, v_mfma_f32_32x32x16_bf16, 32-row tiles streamed through a
+// double-buffered LDS ring by LDS-DMA (buffer_load ... lds, no staging registers, bounds-checked so
+// rows past N arrive as zeros), one barrier per tile.
+// One LDS image serves row reads (ds_read_b128) and transposed reads (ds_read_b64_tr_b16), both
+// conflict-free: rows of RS bytes (256/512), 16-byte chunk index XOR X(row),
+//     X(row) = ((row & 3) << 2) | ((row >> 2) & 3).
+// The DMA writes LDS linearly (wave-uniform base + lane*16), so the XOR is applied to the per-lane
+// SOURCE address (the permutation is an involution inside one 256-B group, so coalescing is kept).
+//
+//   forward : workgroup = 128 query rows; S^T = K Q^T (query on the lane -> a lane owns 16 scores of one
+//             row), P^T straight from the accumulator registers is the B operand of O^T = V^T P^T.
+//   dK, dV  : workgroup = 128 keys, key on the lane, sweeps 32-row Q/dO tiles; S and dP accumulators are
+//             initialised with -LSE/scale and -delta; P and dS feed dV^T = dO^T P, dK^T = Q^T dS.
+//   dQ      : workgroup = 128 query rows, sweeps 32-key K/V tiles; dQ^T = K^T dS^T.
+// Backward is deterministic (no atomics) at the price of recomputing S and dP in both kernels.
 #include "common.h"
 
-#define ATT_KT 64        // keys per LDS tile
-#define ATT_QW 32        // query rows per wave
-
 template <int HDP> struct AttCfg {
-  static constexpr int KS = HDP * 2 + 16;                                  // K row stride (bytes)
-  static constexpr int VS = (HDP * 2 <= 256) ? 256 : ((HDP * 2 <= 512) ? 512 : 1024);  // V row stride (bytes)
-  static constexpr int K_BYTES = ATT_KT * KS;
-  static constexpr int V_BYTES = ATT_KT * VS;
-  static constexpr int CPR = HDP / 8;                                       // 16-B chunks per row
+  static constexpr int RS = (HDP * 2 <= 256) ? 256 : 512;   // LDS row stride in bytes
+  static constexpr int CPR = RS / 16;                        // 16-B chunks per LDS row (incl. pad)
+  static constexpr int RPI = 1024 / RS;                      // rows per DMA wave-instruction
+  static constexpr int TILE = 32 * RS;                       // one 32-row image
+  static constexpr int NDT = HDP / 32;
 };
 
-__device__ __forceinline__ uint32_t v_off(int row, int col, int VS) {
-  const int byte = col * 2;
-  return row * VS + ((((byte >> 6) ^ (row & 3))) << 6) + (byte & 63);
+__device__ __forceinline__ int xr(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ uint32_t u_off(int row, int byte, int RS) {
+  return row * RS + ((((byte >> 4) ^ xr(row))) << 4) + (byte & 15);
 }
 
 __device__ __forceinline__ bf16x8 tr_pair(const char* base, uint32_t o0, uint32_t o1) {
@@ -38,129 +44,131 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* base, uint32_t o0, uint32_
   s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(bf16x8, v);
 }
-
 __device__ __forceinline__ bf16x8 pack8(const float* p) {
   u32x4 u = {pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
   return __builtin_bit_cast(bf16x8, u);
 }
-
-// stage `rows` x HDP bf16 (row-major, row stride ld elements) into an LDS image; rows beyond the
-// buffer extent come back as zeros from the bounds check
-template <int HDP, bool VIMG, int BATCH = 4>
-__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, int64_t row0, int64_t ld, char* lds, int tid) {
-  constexpr int CPR = HDP / 8, TOTAL = ATT_KT * CPR, PER = (TOTAL + 255) / 256;
-#pragma unroll
-  for (int i0 = 0; i0 < PER; i0 += BATCH) {
-    u32x4 reg[BATCH];
-#pragma unroll
-    for (int i = 0; i < BATCH; ++i) {
-      const int e = tid + (i0 + i) * 256;
-      const int r = e / CPR, c = e % CPR;
-      reg[i] = u32x4{0, 0, 0, 0};
-      if (i0 + i < PER && e < TOTAL) reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)(((row0 + r) * ld + c * 8) * 2), 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < BATCH; ++i) {
-      const int e = tid + (i0 + i) * 256;
-      const int r = e / CPR, c = e % CPR;
-      if (i0 + i < PER && e < TOTAL) {
-        const uint32_t off = VIMG ? v_off(r, c * 8, AttCfg<HDP>::VS) : (uint32_t)(r * AttCfg<HDP>::KS + c * 16);
-        *reinterpret_cast<u32x4*>(lds + off) = reg[i];
-      }
-    }
-  }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* p, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 
+// DMA one 32-row image (rows row0.. of a [*, ld] bf16 matrix seen through rs) into lds_img.
+// 4 waves, each issues 32/RPI/4 wave-instructions of 1 KiB.
+template <int HDP>
+__device__ __forceinline__ void dma_tile(__amdgpu_buffer_rsrc_t rs, int row0, int64_t ld, char* lds_img, int wave, int lane) {
+  using C = AttCfg<HDP>;
+  constexpr int NI = 32 / C::RPI / 4;
+  typedef __attribute__((address_space(3))) void lds_void;
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int piece = wave * NI + j;
+    const int row = piece * C::RPI + lane / C::CPR;
+    const int cphys = lane % C::CPR;
+    const int clog = cphys ^ xr(row);
+    const uint32_t voff = (uint32_t)(((int64_t)(row0 + row) * ld) * 2 + clog * 16);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds_img + piece * 1024), 16, voff, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int HDP>
+__device__ __forceinline__ void lds_zero(char* smem, int bytes, int tid) {
+  for (int o = tid * 16; o < bytes; o += 256 * 16) *reinterpret_cast<u32x4*>(smem + o) = u32x4{0, 0, 0, 0};
+}
+
+// ============================================================================================ forward
 template <int HDP, int NKS>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ o,
                                                           float* __restrict__ lse, int N, int H, float c_exp2) {
-  using Cfg = AttCfg<HDP>;
-  constexpr int NDT = HDP / 32;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* ldsK = smem;
-  char* ldsV = smem + Cfg::K_BYTES;
+  using C = AttCfg<HDP>;
+  constexpr int RS = C::RS, NDT = C::NDT, BUF = 2 * C::TILE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K image | V image]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.y, b = blockIdx.z;
   const int64_t ld = 3ll * H * HDP;
-  const int q0 = blockIdx.x * 128 + wave * ATT_QW;
+  const int q0 = blockIdx.x * 128 + wave * 32;
   const uint16_t* base = qkv + (int64_t)b * N * ld;
   const uint32_t extent = (uint32_t)((((int64_t)N - 1) * ld + HDP) * 2);
-  const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(base + h * HDP), 0, extent, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(base + (H + h) * HDP), 0, extent, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(base + (2 * H + h) * HDP), 0, extent, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsQ = mk_rsrc(base + h * HDP, extent);
+  const __amdgpu_buffer_rsrc_t rsK = mk_rsrc(base + (H + h) * HDP, extent);
+  const __amdgpu_buffer_rsrc_t rsV = mk_rsrc(base + (2 * H + h) * HDP, extent);
 
+  lds_zero<HDP>(smem, 2 * BUF, tid);
   const int lq = lane & 31, hh = lane >> 5;
   bf16x8 qf[NKS];
 #pragma unroll
-  for (int s = 0; s < NKS; ++s) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsQ, (uint32_t)((((int64_t)q0 + lq) * ld + 16 * s + 8 * hh) * 2), 0, 0);
-    qf[s] = __builtin_bit_cast(bf16x8, v);
-  }
+  for (int s = 0; s < NKS; ++s)
+    qf[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+        rsQ, (uint32_t)((((int64_t)q0 + lq) * ld + 16 * s + 8 * hh) * 2), 0, 0));
   f32x16 oacc[NDT];
 #pragma unroll
   for (int i = 0; i < NDT; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
-
-  // transposed-read lane constants
   const int gi = lane >> 4, t = lane & 15, tq = t >> 2, tp = t & 3;
-  const int d_in_tile = 16 * (gi & 1) + 4 * tp;   // column offset inside a 32-wide d tile
 
-  const int ntiles = (N + ATT_KT - 1) / ATT_KT;
+  const int ntiles = (N + 31) / 32;
+  __syncthreads();
+  dma_tile<HDP>(rsK, 0, ld, smem, wave, lane);
+  dma_tile<HDP>(rsV, 0, ld, smem + C::TILE, wave, lane);
+  dma_wait();
+  __syncthreads();
   for (int kt = 0; kt < ntiles; ++kt) {
-    __syncthreads();
-    stage_tile<HDP, false>(rsK, (int64_t)kt * ATT_KT, ld, ldsK, tid);
-    stage_tile<HDP, true>(rsV, (int64_t)kt * ATT_KT, ld, ldsV, tid);
-    __syncthreads();
+    const int cur = kt & 1;
+    if (kt + 1 < ntiles) {
+      dma_tile<HDP>(rsK, (kt + 1) * 32, ld, smem + (cur ^ 1) * BUF, wave, lane);
+      dma_tile<HDP>(rsV, (kt + 1) * 32, ld, smem + (cur ^ 1) * BUF + C::TILE, wave, lane);
+    }
+    const char* kimg = smem + cur * BUF;
+    const char* vimg = kimg + C::TILE;
+    const int kbase = kt * 32;
+    f32x16 sacc;
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      const int kbase = kt * ATT_KT + sub * 32;
-      if (kbase >= N) break;
-      f32x16 sacc;
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+    for (int s = 0; s < NKS; ++s) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kimg + u_off(lq, (16 * s + 8 * hh) * 2, RS));
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc, 0, 0, 0);
+    }
+    if (kbase + 32 > N) {
 #pragma unroll
-      for (int s = 0; s < NKS; ++s) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(ldsK + (sub * 32 + lq) * Cfg::KS + (16 * s + 8 * hh) * 2);
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc, 0, 0, 0);
-      }
-      if (kbase + 32 > N) {
+      for (int r = 0; r < 16; ++r)
+        if (kbase + (r & 3) + 8 * (r >> 2) + 4 * hh >= N) sacc[r] = -INFINITY;
+    }
+    float mx = sacc[0];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kbase + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (key >= N) sacc[r] = -INFINITY;
-        }
-      }
-      float mx = sacc[0];
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float mc = m_new * c_exp2;
+    float p[16];
+    float rs = 0.f;
 #pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
+    for (int r = 0; r < 16; ++r) { p[r] = exp2f(sacc[r] * c_exp2 - mc); rs += p[r]; }
+    if (__any(m_new > m_run)) {     // exact: the O rescale is skipped only when no row's max moved
       const float alpha = exp2f((m_run - m_new) * c_exp2);
-      const float mc = m_new * c_exp2;
-      float p[16];
-      float rs = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { p[r] = exp2f(sacc[r] * c_exp2 - mc); rs += p[r]; }
-      l_run = l_run * alpha + rs;
-      m_run = m_new;
+      l_run *= alpha;
 #pragma unroll
       for (int i = 0; i < NDT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-      const bf16x8 pf0 = pack8(p), pf1 = pack8(p + 8);
+      m_run = m_new;
+    }
+    l_run += rs;
+    const bf16x8 pf0 = pack8(p), pf1 = pack8(p + 8);
 #pragma unroll
-      for (int i = 0; i < NDT; ++i) {
-        const int col = i * 32 + d_in_tile;
+    for (int i = 0; i < NDT; ++i) {
+      const int byte = (i * 32 + 16 * (gi & 1) + 4 * tp) * 2;
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const int r0 = sub * 32 + 16 * s2 + 4 * (gi >> 1) + tq;
-          const bf16x8 vf = tr_pair(ldsV, v_off(r0, col, Cfg::VS), v_off(r0 + 8, col, Cfg::VS));
-          oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, s2 == 0 ? pf0 : pf1, oacc[i], 0, 0, 0);
-        }
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int r0 = 16 * s2 + 4 * (gi >> 1) + tq;
+        const bf16x8 vf = tr_pair(vimg, u_off(r0, byte, RS), u_off(r0 + 8, byte, RS));
+        oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, s2 == 0 ? pf0 : pf1, oacc[i], 0, 0, 0);
       }
     }
+    dma_wait();
+    __syncthreads();
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l_tot;
@@ -172,65 +180,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int d = i * 32 + 8 * rr + 4 * hh;
-        u32x2 u = {pack_bf16x2(oacc[i][4 * rr] * inv, oacc[i][4 * rr + 1] * inv),
-                   pack_bf16x2(oacc[i][4 * rr + 2] * inv, oacc[i][4 * rr + 3] * inv)};
-        *reinterpret_cast<u32x2*>(orow + d) = u;
+        *reinterpret_cast<u32x2*>(orow + d) = u32x2{pack_bf16x2(oacc[i][4 * rr] * inv, oacc[i][4 * rr + 1] * inv),
+                                                     pack_bf16x2(oacc[i][4 * rr + 2] * inv, oacc[i][4 * rr + 3] * inv)};
       }
     if (hh == 0) lse[((int64_t)b * H + h) * N + q] = (m_run * c_exp2 + log2f(l_tot)) * 0.6931471805599453f;
   }
 }
 
-template <int HDP, int NKS>
-static int launch_fwd(const void* qkv, void* o, float* lse, int64_t B, int64_t N, int64_t H, float scale, hipStream_t s) {
-  using Cfg = AttCfg<HDP>;
-  const size_t lds = Cfg::K_BYTES + Cfg::V_BYTES;
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HDP, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  dim3 grid((unsigned)((N + 127) / 128), (unsigned)H, (unsigned)B);
-  hipLaunchKernelGGL((attn_fwd_kernel<HDP, NKS>), grid, dim3(256), lds, s, (const uint16_t*)qkv, (uint16_t*)o, lse, (int)N, (int)H,
-                     scale * 1.4426950408889634f);
-  VITA_CHECK_LAUNCH("vita_attn_fwd");
-  return VITA_OK;
-}
-
-extern "C" int vita_attn_supported(int64_t hd, int64_t hdp) {
-  const int64_t nks = (hd + 15) / 16;
-  return (hdp == 224 && nks == 13) || (hdp == 64 && nks == 3) || (hdp == 32 && nks == 2) || (hdp == 128 && nks == 8);
-}
-
-extern "C" int vita_attn_fwd(const void* qkv, void* o, float* lse, int64_t B, int64_t N, int64_t H, int64_t hd, int64_t hdp,
-                             float scale, void* stream) {
-  VITA_REQUIRE(qkv && o && lse && B > 0 && N > 0 && H > 0 && B < 65536 && H < 65536);
-  VITA_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 7) == 0);
-  VITA_REQUIRE(N * 3 * H * hdp * 2 < (int64_t)0xffffffffll);
-  hipStream_t s = (hipStream_t)stream;
-  const int64_t nks = (hd + 15) / 16;
-  if (hdp == 224 && nks == 13) return launch_fwd<224, 13>(qkv, o, lse, B, N, H, scale, s);
-  if (hdp == 64 && nks == 3) return launch_fwd<64, 3>(qkv, o, lse, B, N, H, scale, s);
-  if (hdp == 32 && nks == 2) return launch_fwd<32, 2>(qkv, o, lse, B, N, H, scale, s);
-  if (hdp == 128 && nks == 8) return launch_fwd<128, 8>(qkv, o, lse, B, N, H, scale, s);
-  vita_set_error("vita_attn_fwd: unsupported head dim", hipSuccess);
-  return VITA_ERR_UNSUPPORTED;
-}
-
-// =============================================================================================
-// Backward.  P is recomputed from Q, K and the forward's LSE; no N x N tensor is stored.
-//   delta[q] = rowsum(dO * O)                                  (attn_delta_kernel)
-//   dK, dV : one workgroup = 4 waves = 128 keys of one (b,h), key on the MFMA lane; each wave keeps
-//            dK^T and dV^T of its 32 keys in accumulators while the workgroup sweeps 32-row query
-//            tiles (Q and dO staged in LDS, double buffered, prefetched through registers).
-//   dQ     : one workgroup = 128 query rows, query on the lane; sweeps 64-key K/V tiles.
-// Both are deterministic (no atomics).  S and dP accumulators are initialised with -LSE/scale and
-// -delta so p = exp2(c*S') and dS = p*dP' need no extra subtraction.
-// One LDS image serves row reads (ds_read_b128) and transposed reads (ds_read_b64_tr_b16):
-//   off(row, byte) = row*RS + ((byte>>6 ^ row&3)<<6) + (((byte>>4)&3 ^ (row>>2)&3)<<4) + (byte&15)
-template <int HDP> struct BwdCfg {
-  static constexpr int RS = (HDP * 2 <= 256) ? 256 : ((HDP * 2 <= 512) ? 512 : 1024);
-};
-__device__ __forceinline__ uint32_t u_off(int row, int byte, int RS) {
-  return row * RS + ((((byte >> 6) ^ (row & 3))) << 6) + (((((byte >> 4) & 3) ^ ((row >> 2) & 3))) << 4) + (byte & 15);
-}
-
+// ============================================================================================ backward
 __global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restrict__ o, const uint16_t* __restrict__ dout,
                                                          float* __restrict__ delta, int64_t BN, int N, int H, int HDP) {
   const int lane = threadIdx.x & 63;
@@ -253,52 +210,28 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restr
   }
 }
 
-// stage ROWS x HDP bf16 into the unified image, through registers (load / store split)
-template <int HDP, int ROWS>
-struct UStager {
-  static constexpr int CPR = HDP / 8, TOTAL = ROWS * CPR, PER = (TOTAL + 255) / 256;
-  u32x4 reg[PER];
-  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int64_t row0, int64_t ld, int tid) {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int e = tid + i * 256;
-      const int r = e / CPR, c = e % CPR;
-      reg[i] = u32x4{0, 0, 0, 0};
-      if (e < TOTAL) reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)(((row0 + r) * ld + c * 8) * 2), 0, 0);
-    }
-  }
-  __device__ __forceinline__ void store(char* lds, int tid) {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int e = tid + i * 256;
-      const int r = e / CPR, c = e % CPR;
-      if (e < TOTAL) *reinterpret_cast<u32x4*>(lds + u_off(r, c * 16, BwdCfg<HDP>::RS)) = reg[i];
-    }
-  }
-};
-
 template <int HDP, int NKS>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                uint16_t* __restrict__ dqkv, int N, int H, float scale) {
-  constexpr int RS = BwdCfg<HDP>::RS, NDT = HDP / 32, QT = 32;
-  constexpr int TILE = QT * RS;                 // one image
+  using C = AttCfg<HDP>;
+  constexpr int RS = C::RS, NDT = C::NDT, TILE = C::TILE;
+  constexpr int BUF = 2 * TILE + 256;             // [ Q image | dO image | lse[32] | delta[32] ]
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // [buf][ Q image | dO image | lse[32] | delta[32] ]
-  constexpr int BUF = 2 * TILE + 256;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.y, b = blockIdx.z;
   const int64_t ld = 3ll * H * HDP, ldo = (int64_t)H * HDP;
   const uint16_t* base = qkv + (int64_t)b * N * ld;
   const uint32_t extent = (uint32_t)((((int64_t)N - 1) * ld + HDP) * 2);
   const uint32_t extent_o = (uint32_t)((((int64_t)N - 1) * ldo + HDP) * 2);
-  const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(base + h * HDP), 0, extent, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(base + (H + h) * HDP), 0, extent, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(base + (2 * H + h) * HDP), 0, extent, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsDO = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(dout + (int64_t)b * N * ldo + h * HDP), 0, extent_o, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsQ = mk_rsrc(base + h * HDP, extent);
+  const __amdgpu_buffer_rsrc_t rsK = mk_rsrc(base + (H + h) * HDP, extent);
+  const __amdgpu_buffer_rsrc_t rsV = mk_rsrc(base + (2 * H + h) * HDP, extent);
+  const __amdgpu_buffer_rsrc_t rsDO = mk_rsrc(dout + (int64_t)b * N * ldo + h * HDP, extent_o);
   const float* lse_bh = lse + ((int64_t)b * H + h) * N;
   const float* delta_bh = delta + ((int64_t)b * H + h) * N;
 
+  lds_zero<HDP>(smem, 2 * BUF, tid);
   const int lk = lane & 31, hh = lane >> 5;
   const int key = blockIdx.x * 128 + wave * 32 + lk;
   bf16x8 kf[NKS], vf[NKS];
@@ -313,34 +246,27 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
   for (int i = 0; i < NDT; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[i][r] = 0.f; dv[i][r] = 0.f; }
-
   const float c_exp2 = scale * 1.4426950408889634f, inv_scale = 1.f / scale;
   const int gi = lane >> 4, t = lane & 15, tq = t >> 2, tp = t & 3;
-  const int ntiles = (N + QT - 1) / QT;
+  const int ntiles = (N + 31) / 32;
 
-  UStager<HDP, QT> sq, sdo;
-  float r_ls = 0.f;
-  auto load_tile = [&](int tile) {
-    sq.load(rsQ, (int64_t)tile * QT, ld, tid);
-    sdo.load(rsDO, (int64_t)tile * QT, ldo, tid);
+  auto issue = [&](int tile, int buf) {
+    char* bp = smem + buf * BUF;
+    dma_tile<HDP>(rsQ, tile * 32, ld, bp, wave, lane);
+    dma_tile<HDP>(rsDO, tile * 32, ldo, bp + TILE, wave, lane);
     if (tid < 64) {
-      const int qq = tile * QT + (tid & 31);
-      r_ls = qq < N ? (tid < 32 ? lse_bh[qq] : delta_bh[qq]) : 0.f;
+      const int qq = tile * 32 + (tid & 31);
+      const float v = qq < N ? (tid < 32 ? lse_bh[qq] : delta_bh[qq]) : 0.f;
+      reinterpret_cast<float*>(bp + 2 * TILE)[tid] = v;
     }
   };
-  auto store_tile = [&](int buf) {
-    char* bp = smem + buf * BUF;
-    sq.store(bp, tid);
-    sdo.store(bp + TILE, tid);
-    if (tid < 64) reinterpret_cast<float*>(bp + 2 * TILE)[tid] = r_ls;   // [0,32) lse, [32,64) delta
-  };
-
-  load_tile(0);
-  store_tile(0);
+  __syncthreads();
+  issue(0, 0);
+  dma_wait();
   __syncthreads();
   for (int tile = 0; tile < ntiles; ++tile) {
     const int cur = tile & 1;
-    if (tile + 1 < ntiles) load_tile(tile + 1);
+    if (tile + 1 < ntiles) issue(tile + 1, cur ^ 1);
     const char* qimg = smem + cur * BUF;
     const char* doimg = qimg + TILE;
     const float* ls = reinterpret_cast<const float*>(qimg + 2 * TILE);
@@ -365,6 +291,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
     float p[16], ds[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { p[r] = exp2f(sacc[r] * c_exp2); ds[r] = p[r] * dpacc[r]; }
+    if (tile * 32 + 32 > N) {       // query rows past N: force exact zeros whatever the LDS holds
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= N) { p[r] = 0.f; ds[r] = 0.f; }
+    }
     const bf16x8 pf0 = pack8(p), pf1 = pack8(p + 8), df0 = pack8(ds), df1 = pack8(ds + 8);
 #pragma unroll
     for (int i = 0; i < NDT; ++i) {
@@ -379,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
         dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT, s2 == 0 ? df0 : df1, dk[i], 0, 0, 0);
       }
     }
-    if (tile + 1 < ntiles) store_tile(cur ^ 1);
+    dma_wait();
     __syncthreads();
   }
   if (key < N) {
@@ -402,8 +333,8 @@ template <int HDP, int NKS>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
                                                              uint16_t* __restrict__ dqkv, int N, int H, float scale) {
-  constexpr int RS = BwdCfg<HDP>::RS, NDT = HDP / 32, KT = 64;
-  constexpr int TILE = KT * RS, BUF = 2 * TILE;
+  using C = AttCfg<HDP>;
+  constexpr int RS = C::RS, NDT = C::NDT, TILE = C::TILE, BUF = 2 * TILE;   // [ K image | V image ]
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.y, b = blockIdx.z;
@@ -411,11 +342,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
   const uint16_t* base = qkv + (int64_t)b * N * ld;
   const uint32_t extent = (uint32_t)((((int64_t)N - 1) * ld + HDP) * 2);
   const uint32_t extent_o = (uint32_t)((((int64_t)N - 1) * ldo + HDP) * 2);
-  const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(base + h * HDP), 0, extent, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(base + (H + h) * HDP), 0, extent, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(base + (2 * H + h) * HDP), 0, extent, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsDO = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(dout + (int64_t)b * N * ldo + h * HDP), 0, extent_o, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsQ = mk_rsrc(base + h * HDP, extent);
+  const __amdgpu_buffer_rsrc_t rsK = mk_rsrc(base + (H + h) * HDP, extent);
+  const __amdgpu_buffer_rsrc_t rsV = mk_rsrc(base + (2 * H + h) * HDP, extent);
+  const __amdgpu_buffer_rsrc_t rsDO = mk_rsrc(dout + (int64_t)b * N * ldo + h * HDP, extent_o);
 
+  lds_zero<HDP>(smem, 2 * BUF, tid);
   const int lq = lane & 31, hh = lane >> 5;
   const int q = blockIdx.x * 128 + wave * 32 + lq;
   bf16x8 qf[NKS], dof[NKS];
@@ -433,54 +365,55 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
   const int gi = lane >> 4, t = lane & 15, tq = t >> 2, tp = t & 3;
-  const int ntiles = (N + KT - 1) / KT;
+  const int ntiles = (N + 31) / 32;
 
-  UStager<HDP, KT> sk, sv;
-  sk.load(rsK, 0, ld, tid); sv.load(rsV, 0, ld, tid);
-  sk.store(smem, tid); sv.store(smem + TILE, tid);
+  __syncthreads();
+  dma_tile<HDP>(rsK, 0, ld, smem, wave, lane);
+  dma_tile<HDP>(rsV, 0, ld, smem + TILE, wave, lane);
+  dma_wait();
   __syncthreads();
   for (int tile = 0; tile < ntiles; ++tile) {
     const int cur = tile & 1;
-    if (tile + 1 < ntiles) { sk.load(rsK, (int64_t)(tile + 1) * KT, ld, tid); sv.load(rsV, (int64_t)(tile + 1) * KT, ld, tid); }
+    if (tile + 1 < ntiles) {
+      dma_tile<HDP>(rsK, (tile + 1) * 32, ld, smem + (cur ^ 1) * BUF, wave, lane);
+      dma_tile<HDP>(rsV, (tile + 1) * 32, ld, smem + (cur ^ 1) * BUF + TILE, wave, lane);
+    }
     const char* kimg = smem + cur * BUF;
     const char* vimg = kimg + TILE;
+    const int kbase = tile * 32;
+    f32x16 sacc, dpacc;
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-      const int kbase = tile * KT + sub * 32;
-      if (kbase < N) {
-        f32x16 sacc, dpacc;
+    for (int r = 0; r < 16; ++r) { sacc[r] = s_init; dpacc[r] = d_init; }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sacc[r] = s_init; dpacc[r] = d_init; }
+    for (int s = 0; s < NKS; ++s) {
+      const bf16x8 ka = *reinterpret_cast<const bf16x8*>(kimg + u_off(lq, (16 * s + 8 * hh) * 2, RS));
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], sacc, 0, 0, 0);
+    }
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-          const bf16x8 ka = *reinterpret_cast<const bf16x8*>(kimg + u_off(sub * 32 + lq, (16 * s + 8 * hh) * 2, RS));
-          sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], sacc, 0, 0, 0);
-        }
+    for (int s = 0; s < NKS; ++s) {
+      const bf16x8 va = *reinterpret_cast<const bf16x8*>(vimg + u_off(lq, (16 * s + 8 * hh) * 2, RS));
+      dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[s], dpacc, 0, 0, 0);
+    }
+    float ds[16];
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-          const bf16x8 va = *reinterpret_cast<const bf16x8*>(vimg + u_off(sub * 32 + lq, (16 * s + 8 * hh) * 2, RS));
-          dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[s], dpacc, 0, 0, 0);
-        }
-        float ds[16];
+    for (int r = 0; r < 16; ++r) ds[r] = exp2f(sacc[r] * c_exp2) * dpacc[r];
+    if (kbase + 32 > N) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int kk = kbase + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          ds[r] = kk < N ? exp2f(sacc[r] * c_exp2) * dpacc[r] : 0.f;
-        }
-        const bf16x8 df0 = pack8(ds), df1 = pack8(ds + 8);
+      for (int r = 0; r < 16; ++r)
+        if (kbase + (r & 3) + 8 * (r >> 2) + 4 * hh >= N) ds[r] = 0.f;
+    }
+    const bf16x8 df0 = pack8(ds), df1 = pack8(ds + 8);
 #pragma unroll
-        for (int i = 0; i < NDT; ++i) {
-          const int byte = (i * 32 + 16 * (gi & 1) + 4 * tp) * 2;
+    for (int i = 0; i < NDT; ++i) {
+      const int byte = (i * 32 + 16 * (gi & 1) + 4 * tp) * 2;
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            const int r0 = sub * 32 + 16 * s2 + 4 * (gi >> 1) + tq;
-            const bf16x8 kT = tr_pair(kimg, u_off(r0, byte, RS), u_off(r0 + 8, byte, RS));
-            dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT, s2 == 0 ? df0 : df1, dq[i], 0, 0, 0);
-          }
-        }
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int r0 = 16 * s2 + 4 * (gi >> 1) + tq;
+        const bf16x8 kT = tr_pair(kimg, u_off(r0, byte, RS), u_off(r0 + 8, byte, RS));
+        dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT, s2 == 0 ? df0 : df1, dq[i], 0, 0, 0);
       }
     }
-    if (tile + 1 < ntiles) { sk.store(smem + (cur ^ 1) * BUF, tid); sv.store(smem + (cur ^ 1) * BUF + TILE, tid); }
+    dma_wait();
     __syncthreads();
   }
   if (q < N) {
@@ -496,11 +429,23 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
   }
 }
 
+// ============================================================================================ host
+template <int HDP, int NKS>
+static int launch_fwd(const void* qkv, void* o, float* lse, int64_t B, int64_t N, int64_t H, float scale, hipStream_t s) {
+  const size_t lds = 4 * AttCfg<HDP>::TILE;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HDP, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  dim3 grid((unsigned)((N + 127) / 128), (unsigned)H, (unsigned)B);
+  hipLaunchKernelGGL((attn_fwd_kernel<HDP, NKS>), grid, dim3(256), lds, s, (const uint16_t*)qkv, (uint16_t*)o, lse, (int)N, (int)H,
+                     scale * 1.4426950408889634f);
+  VITA_CHECK_LAUNCH("vita_attn_fwd");
+  return VITA_OK;
+}
+
 template <int HDP, int NKS>
 static int launch_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, int64_t B,
                       int64_t N, int64_t H, float scale, hipStream_t s) {
-  constexpr int RS = BwdCfg<HDP>::RS;
-  const size_t lds_kv = 2 * (2 * 32 * RS + 256), lds_q = 2 * (2 * 64 * RS);
+  const size_t lds_kv = 2 * (2 * AttCfg<HDP>::TILE + 256), lds_q = 4 * AttCfg<HDP>::TILE;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<HDP, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
@@ -520,6 +465,31 @@ static int launch_bwd(const void* qkv, const void* o, const void* dout, const fl
   return VITA_OK;
 }
 
+#define ATT_DISPATCH(CALL)                                   \
+  if (hdp == 224 && nks == 13) return CALL(224, 13);         \
+  if (hdp == 64 && nks == 3) return CALL(64, 3);             \
+  if (hdp == 32 && nks == 2) return CALL(32, 2);             \
+  if (hdp == 128 && nks == 8) return CALL(128, 8);
+
+extern "C" int vita_attn_supported(int64_t hd, int64_t hdp) {
+  const int64_t nks = (hd + 15) / 16;
+  return (hdp == 224 && nks == 13) || (hdp == 64 && nks == 3) || (hdp == 32 && nks == 2) || (hdp == 128 && nks == 8);
+}
+
+extern "C" int vita_attn_fwd(const void* qkv, void* o, float* lse, int64_t B, int64_t N, int64_t H, int64_t hd, int64_t hdp,
+                             float scale, void* stream) {
+  VITA_REQUIRE(qkv && o && lse && B > 0 && N > 0 && H > 0 && B < 65536 && H < 65536);
+  VITA_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 7) == 0);
+  VITA_REQUIRE(N * 3 * H * hdp * 2 < (int64_t)0xffffffffll);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nks = (hd + 15) / 16;
+#define FWD_CALL(A, K) launch_fwd<A, K>(qkv, o, lse, B, N, H, scale, s)
+  ATT_DISPATCH(FWD_CALL)
+#undef FWD_CALL
+  vita_set_error("vita_attn_fwd: unsupported head dim", hipSuccess);
+  return VITA_ERR_UNSUPPORTED;
+}
+
 extern "C" int vita_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv,
                              int64_t B, int64_t N, int64_t H, int64_t hd, int64_t hdp, float scale, void* stream) {
   VITA_REQUIRE(qkv && o && dout && lse && delta && dqkv && B > 0 && N > 0 && H > 0 && B < 65536 && H < 65536);
@@ -527,10 +497,9 @@ extern "C" int vita_attn_bwd(const void* qkv, const void* o, const void* dout, c
   VITA_REQUIRE(N * 3 * H * hdp * 2 < (int64_t)0xffffffffll);
   hipStream_t s = (hipStream_t)stream;
   const int64_t nks = (hd + 15) / 16;
-  if (hdp == 224 && nks == 13) return launch_bwd<224, 13>(qkv, o, dout, lse, delta, dqkv, B, N, H, scale, s);
-  if (hdp == 64 && nks == 3) return launch_bwd<64, 3>(qkv, o, dout, lse, delta, dqkv, B, N, H, scale, s);
-  if (hdp == 32 && nks == 2) return launch_bwd<32, 2>(qkv, o, dout, lse, delta, dqkv, B, N, H, scale, s);
-  if (hdp == 128 && nks == 8) return launch_bwd<128, 8>(qkv, o, dout, lse, delta, dqkv, B, N, H, scale, s);
+#define BWD_CALL(A, K) launch_bwd<A, K>(qkv, o, dout, lse, delta, dqkv, B, N, H, scale, s)
+  ATT_DISPATCH(BWD_CALL)
+#undef BWD_CALL
   vita_set_error("vita_attn_bwd: unsupported head dim", hipSuccess);
   return VITA_ERR_UNSUPPORTED;
 }

@@ -69,25 +69,27 @@ extern "C" int vita_layernorm_fwd(const float* x, int64_t ldx, const float* gamm
   return VITA_OK;
 }
 
-#define LN_BWD_MAXBLK 512
+#define LN_BWD_MAXBLK 256
 extern "C" int64_t vita_layernorm_bwd_nblk(int64_t rows) {
   int64_t n = (rows + 3) / 4;
   return n < LN_BWD_MAXBLK ? n : LN_BWD_MAXBLK;
 }
 
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy, int64_t lddy, int dy_f32,
+// NV = float4 per lane (d <= NV*256).  One wave per row; per-lane dgamma/dbeta partials live in
+// registers across the rows a wave owns and are reduced over the block's 4 waves through LDS.
+template <int NV>
+__global__ __launch_bounds__(256, 2) void ln_bwd_kernel(const void* __restrict__ dy, int64_t lddy, int dy_f32,
                                                      const float* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ dx_in,
                                                      float* __restrict__ dx_out, int64_t lddx, uint16_t* __restrict__ dxb,
                                                      int64_t ld_dxb, float* __restrict__ partial, int64_t rows, int d) {
-  __shared__ float red[2][4][LN_MAXV * 256];   // 64 KB
+  __shared__ float red[2][NV * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nblk = gridDim.x;
-  f32x4 g[LN_MAXV];
-  f32x4 ag[LN_MAXV], ab[LN_MAXV];
+  f32x4 g[NV], ag[NV], ab[NV];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
     ag[i] = ab[i] = g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -95,10 +97,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
   }
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)nblk * 4) {
     const float mu = mean[row], rs = rstd[row];
-    f32x4 xh[LN_MAXV], dyv[LN_MAXV];
+    f32x4 xh[NV], dyv[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
       xh[i] = dyv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (c < d) {
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
     }
     const float c1 = wave_sum(s1) / (float)d, c2 = wave_sum(s2) / (float)d;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (c >= lddx) continue;
       f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -137,27 +139,40 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ dy
         *reinterpret_cast<u32x2*>(dxb + row * ld_dxb + c) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
     }
   }
-  // block reduce of dgamma/dbeta partials over the 4 waves
+  // block reduce over the 4 waves, one wave at a time
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int c = (i * 64 + lane) * 4;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { red[0][wave][c + r] = ag[i][r]; red[1][wave][c + r] = ab[i][r]; }
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        f32x4 a = ag[i], b = ab[i];
+        if (w > 0) { a += *reinterpret_cast<f32x4*>(&red[0][c]); b += *reinterpret_cast<f32x4*>(&red[1][c]); }
+        *reinterpret_cast<f32x4*>(&red[0][c]) = a; *reinterpret_cast<f32x4*>(&red[1][c]) = b;
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
   for (int c = threadIdx.x; c < d; c += 256) {
-    partial[(int64_t)blockIdx.x * d + c] = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
-    partial[((int64_t)nblk + blockIdx.x) * d + c] = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    partial[(int64_t)blockIdx.x * d + c] = red[0][c];
+    partial[((int64_t)nblk + blockIdx.x) * d + c] = red[1][c];
   }
 }
 
-__global__ void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblk, int d, float* __restrict__ dgamma,
-                                     float* __restrict__ dbeta) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= d) return;
+// 64 columns x 4 row groups per block
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblk, int d, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta) {
+  __shared__ float red[2][4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
   float a = 0.f, b = 0.f;
-  for (int k = 0; k < nblk; ++k) { a += partial[(int64_t)k * d + c]; b += partial[((int64_t)nblk + k) * d + c]; }
-  dgamma[c] = a; dbeta[c] = b;
+  if (c < d)
+    for (int k = ry; k < nblk; k += 4) { a += partial[(int64_t)k * d + c]; b += partial[((int64_t)nblk + k) * d + c]; }
+  red[0][ry][cx] = a; red[1][ry][cx] = b;
+  __syncthreads();
+  if (ry == 0 && c < d) {
+    dgamma[c] = red[0][0][cx] + red[0][1][cx] + red[0][2][cx] + red[0][3][cx];
+    dbeta[c] = red[1][0][cx] + red[1][1][cx] + red[1][2][cx] + red[1][3][cx];
+  }
 }
 
 extern "C" int vita_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx,
@@ -169,10 +184,17 @@ extern "C" int vita_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype
   VITA_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && lddx >= d && ldx >= ((d + 3) / 4) * 4 && lddy >= ((d + 3) / 4) * 4);
   if (dx_bf16) VITA_REQUIRE(ld_dxb % 4 == 0 && ld_dxb <= lddx);
   const int nblk = (int)vita_layernorm_bwd_nblk(rows);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, lddy, dy_dtype == VITA_DT_F32, x,
-                     ldx, gamma, mean, rstd, dx_in, dx_out, lddx, (uint16_t*)dx_bf16, ld_dxb, partial, rows, (int)d);
+  const int64_t width = lddx > d ? lddx : d;
+#define LN_BWD_LAUNCH(NV)                                                                                                   \
+  hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, dy, lddy, dy_dtype == VITA_DT_F32, x, \
+                     ldx, gamma, mean, rstd, dx_in, dx_out, lddx, (uint16_t*)dx_bf16, ld_dxb, partial, rows, (int)d)
+  if (width <= 256) LN_BWD_LAUNCH(1);
+  else if (width <= 512) LN_BWD_LAUNCH(2);
+  else if (width <= 1280) LN_BWD_LAUNCH(5);
+  else LN_BWD_LAUNCH(8);
+#undef LN_BWD_LAUNCH
   VITA_CHECK_LAUNCH("vita_layernorm_bwd");
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial,
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((d + 63) / 64)), dim3(256), 0, (hipStream_t)stream, partial,
                      nblk, (int)d, dgamma, dbeta);
   VITA_CHECK_LAUNCH("vita_layernorm_bwd_reduce");
   return VITA_OK;
