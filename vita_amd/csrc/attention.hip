@@ -22,6 +22,7 @@
 //   dQ      : workgroup = 128 query rows, sweeps 32-key K/V tiles; dQ^T = K^T dS^T.
 // Backward is deterministic (no atomics) at the price of recomputing S and dP in both kernels.
 #include "common.h"
+#include <type_traits>
 
 template <int HDP> struct AttCfg {
   static constexpr int RS = (HDP * 2 <= 256) ? 256 : 512;   // LDS row stride in bytes
@@ -44,10 +45,54 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* base, uint32_t o0, uint32_
   s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(bf16x8, v);
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk(float lo, float hi) {   // one v_cvt_pk_bf16_f32
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
 __device__ __forceinline__ bf16x8 pack8(const float* p) {
-  u32x4 u = {pack_bf16x2(p[0], p[1]), pack_bf16x2(p[2], p[3]), pack_bf16x2(p[4], p[5]), pack_bf16x2(p[6], p[7])};
+  u32x4 u = {cvt_pk(p[0], p[1]), cvt_pk(p[2], p[3]), cvt_pk(p[4], p[5]), cvt_pk(p[6], p[7])};
   return __builtin_bit_cast(bf16x8, u);
 }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // bare v_exp_f32
+
+// Per-lane LDS byte offsets inside one 32-row image, arranged so that every access in the tile loop is
+// base register + compile-time immediate (no address arithmetic in the loop):
+//   row read, k-step s      : rb[s & 7] + 256 * (s >> 3)
+//   transposed read (i,s2,u): tb[i & 3][u] + 256 * (i >> 2) + (16*s2 + 8*u) * RS     (u = second half)
+template <int HDP, int NKS>
+struct LdsAddr {
+  static constexpr int RS = AttCfg<HDP>::RS;
+  static constexpr int NRB = NKS < 8 ? NKS : 8;
+  static constexpr int NTB = AttCfg<HDP>::NDT < 4 ? AttCfg<HDP>::NDT : 4;
+  uint32_t rb[NRB];
+  uint32_t tb[NTB][2];
+  __device__ __forceinline__ void init(int lane) {
+    const int lrow = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < NRB; ++j) rb[j] = lrow * RS + ((((2 * j + hh) ^ xr(lrow)) & 15) << 4);
+    const int gi = lane >> 4, t = lane & 15, tq = t >> 2, tp = t & 3;
+#pragma unroll
+    for (int j = 0; j < NTB; ++j)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int xlow = ((gi >> 1) + 2 * u) & 3;
+        tb[j][u] = (4 * (gi >> 1) + tq) * RS + ((4 * (j ^ tq) + ((2 * (gi & 1) + (tp >> 1)) ^ xlow)) << 4) + 8 * (tp & 1);
+      }
+  }
+  __device__ __forceinline__ void toggle(int bytes) {   // switch ring buffer (bytes = power of two)
+#pragma unroll
+    for (int j = 0; j < NRB; ++j) rb[j] ^= bytes;
+#pragma unroll
+    for (int j = 0; j < NTB; ++j) { tb[j][0] ^= bytes; tb[j][1] ^= bytes; }
+  }
+  __device__ __forceinline__ bf16x8 row(const char* img, int s) const {
+    return *reinterpret_cast<const bf16x8*>(img + rb[s & 7] + 256 * (s >> 3));
+  }
+  __device__ __forceinline__ bf16x8 tr(const char* img, int i, int s2) const {
+    return tr_pair(img, tb[i & 3][0] + 256 * (i >> 2) + (16 * s2) * RS, tb[i & 3][1] + 256 * (i >> 2) + (16 * s2 + 8) * RS);
+  }
+};
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* p, uint32_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
@@ -109,6 +154,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
   const int gi = lane >> 4, t = lane & 15, tq = t >> 2, tp = t & 3;
 
   const int ntiles = (N + 31) / 32;
+  LdsAddr<HDP, NKS> la;
+  la.init(lane);
   __syncthreads();
   dma_tile<HDP>(rsK, 0, ld, smem, wave, lane);
   dma_tile<HDP>(rsV, 0, ld, smem + C::TILE, wave, lane);
@@ -120,17 +167,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
       dma_tile<HDP>(rsK, (kt + 1) * 32, ld, smem + (cur ^ 1) * BUF, wave, lane);
       dma_tile<HDP>(rsV, (kt + 1) * 32, ld, smem + (cur ^ 1) * BUF + C::TILE, wave, lane);
     }
-    const char* kimg = smem + cur * BUF;
-    const char* vimg = kimg + C::TILE;
+    const char* kimg = smem;            // the ring position lives in the address bases (la.toggle)
+    const char* vimg = smem + C::TILE;
     const int kbase = kt * 32;
     f32x16 sacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kimg + u_off(lq, (16 * s + 8 * hh) * 2, RS));
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc, 0, 0, 0);
-    }
+    for (int s = 0; s < NKS; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.row(kimg, s), qf[s], sacc, 0, 0, 0);
     if (kbase + 32 > N) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
@@ -145,9 +189,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
     float p[16];
     float rs = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { p[r] = exp2f(sacc[r] * c_exp2 - mc); rs += p[r]; }
+    for (int r = 0; r < 16; ++r) { p[r] = fast_exp2(sacc[r] * c_exp2 - mc); rs += p[r]; }
     if (__any(m_new > m_run)) {     // exact: the O rescale is skipped only when no row's max moved
-      const float alpha = exp2f((m_run - m_new) * c_exp2);
+      const float alpha = fast_exp2((m_run - m_new) * c_exp2);
       l_run *= alpha;
 #pragma unroll
       for (int i = 0; i < NDT; ++i)
@@ -159,14 +203,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
     const bf16x8 pf0 = pack8(p), pf1 = pack8(p + 8);
 #pragma unroll
     for (int i = 0; i < NDT; ++i) {
-      const int byte = (i * 32 + 16 * (gi & 1) + 4 * tp) * 2;
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int r0 = 16 * s2 + 4 * (gi >> 1) + tq;
-        const bf16x8 vf = tr_pair(vimg, u_off(r0, byte, RS), u_off(r0 + 8, byte, RS));
-        oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, s2 == 0 ? pf0 : pf1, oacc[i], 0, 0, 0);
-      }
+      oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(vimg, i, 0), pf0, oacc[i], 0, 0, 0);
+      oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(vimg, i, 1), pf1, oacc[i], 0, 0, 0);
     }
+    la.toggle(BUF);
     dma_wait();
     __syncthreads();
   }
@@ -180,8 +220,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int d = i * 32 + 8 * rr + 4 * hh;
-        *reinterpret_cast<u32x2*>(orow + d) = u32x2{pack_bf16x2(oacc[i][4 * rr] * inv, oacc[i][4 * rr + 1] * inv),
-                                                     pack_bf16x2(oacc[i][4 * rr + 2] * inv, oacc[i][4 * rr + 3] * inv)};
+        *reinterpret_cast<u32x2*>(orow + d) = u32x2{cvt_pk(oacc[i][4 * rr] * inv, oacc[i][4 * rr + 1] * inv),
+                                                     cvt_pk(oacc[i][4 * rr + 2] * inv, oacc[i][4 * rr + 3] * inv)};
       }
     if (hh == 0) lse[((int64_t)b * H + h) * N + q] = (m_run * c_exp2 + log2f(l_tot)) * 0.6931471805599453f;
   }
@@ -216,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
                                                                uint16_t* __restrict__ dqkv, int N, int H, float scale) {
   using C = AttCfg<HDP>;
   constexpr int RS = C::RS, NDT = C::NDT, TILE = C::TILE;
-  constexpr int BUF = 2 * TILE + 256;             // [ Q image | dO image | lse[32] | delta[32] ]
+  constexpr int BUF = 2 * TILE;                   // ring slot = [ Q image | dO image ]; lse/delta[2][64] after the ring
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.y, b = blockIdx.z;
@@ -231,7 +271,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
   const float* lse_bh = lse + ((int64_t)b * H + h) * N;
   const float* delta_bh = delta + ((int64_t)b * H + h) * N;
 
-  lds_zero<HDP>(smem, 2 * BUF, tid);
+  lds_zero<HDP>(smem, 2 * BUF + 512, tid);
   const int lk = lane & 31, hh = lane >> 5;
   const int key = blockIdx.x * 128 + wave * 32 + lk;
   bf16x8 kf[NKS], vf[NKS];
@@ -257,9 +297,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
     if (tid < 64) {
       const int qq = tile * 32 + (tid & 31);
       const float v = qq < N ? (tid < 32 ? lse_bh[qq] : delta_bh[qq]) : 0.f;
-      reinterpret_cast<float*>(bp + 2 * TILE)[tid] = v;
+      reinterpret_cast<float*>(smem + 2 * BUF + buf * 256)[tid] = v;
     }
   };
+  LdsAddr<HDP, NKS> la;
+  la.init(lane);
   __syncthreads();
   issue(0, 0);
   dma_wait();
@@ -267,9 +309,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
   for (int tile = 0; tile < ntiles; ++tile) {
     const int cur = tile & 1;
     if (tile + 1 < ntiles) issue(tile + 1, cur ^ 1);
-    const char* qimg = smem + cur * BUF;
-    const char* doimg = qimg + TILE;
-    const float* ls = reinterpret_cast<const float*>(qimg + 2 * TILE);
+    const char* qimg = smem;
+    const char* doimg = smem + TILE;
+    const float* ls = reinterpret_cast<const float*>(smem + 2 * BUF + cur * 256);
     f32x16 sacc, dpacc;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -279,18 +321,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
       for (int k = 0; k < 4; ++k) { sacc[4 * rr + k] = -l4[k] * inv_scale; dpacc[4 * rr + k] = -d4[k]; }
     }
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-      const bf16x8 qa = *reinterpret_cast<const bf16x8*>(qimg + u_off(lk, (16 * s + 8 * hh) * 2, RS));
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[s], sacc, 0, 0, 0);
-    }
+    for (int s = 0; s < NKS; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.row(qimg, s), kf[s], sacc, 0, 0, 0);
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-      const bf16x8 da = *reinterpret_cast<const bf16x8*>(doimg + u_off(lk, (16 * s + 8 * hh) * 2, RS));
-      dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[s], dpacc, 0, 0, 0);
-    }
+    for (int s = 0; s < NKS; ++s) dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.row(doimg, s), vf[s], dpacc, 0, 0, 0);
     float p[16], ds[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { p[r] = exp2f(sacc[r] * c_exp2); ds[r] = p[r] * dpacc[r]; }
+    for (int r = 0; r < 16; ++r) { p[r] = fast_exp2(sacc[r] * c_exp2); ds[r] = p[r] * dpacc[r]; }
     if (tile * 32 + 32 > N) {       // query rows past N: force exact zeros whatever the LDS holds
 #pragma unroll
       for (int r = 0; r < 16; ++r)
@@ -299,17 +335,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
     const bf16x8 pf0 = pack8(p), pf1 = pack8(p + 8), df0 = pack8(ds), df1 = pack8(ds + 8);
 #pragma unroll
     for (int i = 0; i < NDT; ++i) {
-      const int byte = (i * 32 + 16 * (gi & 1) + 4 * tp) * 2;
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int r0 = 16 * s2 + 4 * (gi >> 1) + tq;
-        const uint32_t o0 = u_off(r0, byte, RS), o1 = u_off(r0 + 8, byte, RS);
-        const bf16x8 doT = tr_pair(doimg, o0, o1);
-        dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(doT, s2 == 0 ? pf0 : pf1, dv[i], 0, 0, 0);
-        const bf16x8 qT = tr_pair(qimg, o0, o1);
-        dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qT, s2 == 0 ? df0 : df1, dk[i], 0, 0, 0);
-      }
+      dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(doimg, i, 0), pf0, dv[i], 0, 0, 0);
+      dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(qimg, i, 0), df0, dk[i], 0, 0, 0);
+      dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(doimg, i, 1), pf1, dv[i], 0, 0, 0);
+      dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(qimg, i, 1), df1, dk[i], 0, 0, 0);
     }
+    la.toggle(BUF);
     dma_wait();
     __syncthreads();
   }
@@ -321,10 +352,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int d = i * 32 + 8 * rr + 4 * hh;
-        *reinterpret_cast<u32x2*>(krow + d) = u32x2{pack_bf16x2(dk[i][4 * rr] * scale, dk[i][4 * rr + 1] * scale),
-                                                     pack_bf16x2(dk[i][4 * rr + 2] * scale, dk[i][4 * rr + 3] * scale)};
-        *reinterpret_cast<u32x2*>(vrow + d) = u32x2{pack_bf16x2(dv[i][4 * rr], dv[i][4 * rr + 1]),
-                                                     pack_bf16x2(dv[i][4 * rr + 2], dv[i][4 * rr + 3])};
+        *reinterpret_cast<u32x2*>(krow + d) = u32x2{cvt_pk(dk[i][4 * rr] * scale, dk[i][4 * rr + 1] * scale),
+                                                     cvt_pk(dk[i][4 * rr + 2] * scale, dk[i][4 * rr + 3] * scale)};
+        *reinterpret_cast<u32x2*>(vrow + d) = u32x2{cvt_pk(dv[i][4 * rr], dv[i][4 * rr + 1]),
+                                                     cvt_pk(dv[i][4 * rr + 2], dv[i][4 * rr + 3])};
       }
   }
 }
@@ -367,6 +398,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
   const int gi = lane >> 4, t = lane & 15, tq = t >> 2, tp = t & 3;
   const int ntiles = (N + 31) / 32;
 
+  LdsAddr<HDP, NKS> la;
+  la.init(lane);
   __syncthreads();
   dma_tile<HDP>(rsK, 0, ld, smem, wave, lane);
   dma_tile<HDP>(rsV, 0, ld, smem + TILE, wave, lane);
@@ -378,25 +411,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
       dma_tile<HDP>(rsK, (tile + 1) * 32, ld, smem + (cur ^ 1) * BUF, wave, lane);
       dma_tile<HDP>(rsV, (tile + 1) * 32, ld, smem + (cur ^ 1) * BUF + TILE, wave, lane);
     }
-    const char* kimg = smem + cur * BUF;
-    const char* vimg = kimg + TILE;
+    const char* kimg = smem;
+    const char* vimg = smem + TILE;
     const int kbase = tile * 32;
     f32x16 sacc, dpacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sacc[r] = s_init; dpacc[r] = d_init; }
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-      const bf16x8 ka = *reinterpret_cast<const bf16x8*>(kimg + u_off(lq, (16 * s + 8 * hh) * 2, RS));
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], sacc, 0, 0, 0);
-    }
+    for (int s = 0; s < NKS; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.row(kimg, s), qf[s], sacc, 0, 0, 0);
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-      const bf16x8 va = *reinterpret_cast<const bf16x8*>(vimg + u_off(lq, (16 * s + 8 * hh) * 2, RS));
-      dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[s], dpacc, 0, 0, 0);
-    }
+    for (int s = 0; s < NKS; ++s) dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.row(vimg, s), dof[s], dpacc, 0, 0, 0);
     float ds[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ds[r] = exp2f(sacc[r] * c_exp2) * dpacc[r];
+    for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(sacc[r] * c_exp2) * dpacc[r];
     if (kbase + 32 > N) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
@@ -405,14 +432,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
     const bf16x8 df0 = pack8(ds), df1 = pack8(ds + 8);
 #pragma unroll
     for (int i = 0; i < NDT; ++i) {
-      const int byte = (i * 32 + 16 * (gi & 1) + 4 * tp) * 2;
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int r0 = 16 * s2 + 4 * (gi >> 1) + tq;
-        const bf16x8 kT = tr_pair(kimg, u_off(r0, byte, RS), u_off(r0 + 8, byte, RS));
-        dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT, s2 == 0 ? df0 : df1, dq[i], 0, 0, 0);
-      }
+      dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(kimg, i, 0), df0, dq[i], 0, 0, 0);
+      dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(kimg, i, 1), df1, dq[i], 0, 0, 0);
     }
+    la.toggle(BUF);
     dma_wait();
     __syncthreads();
   }
@@ -423,8 +446,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const int d = i * 32 + 8 * rr + 4 * hh;
-        *reinterpret_cast<u32x2*>(qrow + d) = u32x2{pack_bf16x2(dq[i][4 * rr] * scale, dq[i][4 * rr + 1] * scale),
-                                                     pack_bf16x2(dq[i][4 * rr + 2] * scale, dq[i][4 * rr + 3] * scale)};
+        *reinterpret_cast<u32x2*>(qrow + d) = u32x2{cvt_pk(dq[i][4 * rr] * scale, dq[i][4 * rr + 1] * scale),
+                                                     cvt_pk(dq[i][4 * rr + 2] * scale, dq[i][4 * rr + 3] * scale)};
       }
   }
 }
@@ -445,7 +468,7 @@ static int launch_fwd(const void* qkv, void* o, float* lse, int64_t B, int64_t N
 template <int HDP, int NKS>
 static int launch_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, int64_t B,
                       int64_t N, int64_t H, float scale, hipStream_t s) {
-  const size_t lds_kv = 2 * (2 * AttCfg<HDP>::TILE + 256), lds_q = 4 * AttCfg<HDP>::TILE;
+  const size_t lds_kv = 4 * AttCfg<HDP>::TILE + 512, lds_q = 4 * AttCfg<HDP>::TILE;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<HDP, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
