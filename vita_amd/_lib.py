@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvita_hip.so")
+LIB_PATH = os.environ.get("VITA_AMD_LIB") or os.path.join(_HERE, "libvita_hip.so")   # env override: kernel experiments
 
 i64, i32, f32, vp = C.c_int64, C.c_int32, C.c_float, C.c_void_p
 

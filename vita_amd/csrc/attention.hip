@@ -97,6 +97,28 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* p, uint32_
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 
+
+// Two independent row-read -> MFMA accumulation chains (S and dP), software pipelined DEPTH k-steps
+// ahead so the ds_read_b128 latency is covered by the other chain's MFMAs; the order is pinned with
+// sched_barrier because hipcc otherwise serialises read -> wait -> MFMA when registers are tight.
+template <int HDP, int NKS, int DEPTH>
+__device__ __forceinline__ void dual_chain(f32x16& acc0, f32x16& acc1, const char* img0, const char* img1,
+                                           const LdsAddr<HDP, NKS>& la, const bf16x8 (&b0)[NKS], const bf16x8 (&b1)[NKS]) {
+  bf16x8 a0[DEPTH], a1[DEPTH];
+#pragma unroll
+  for (int j = 0; j < DEPTH && j < NKS; ++j) { a0[j] = la.row(img0, j); a1[j] = la.row(img1, j); }
+#pragma unroll
+  for (int s = 0; s < NKS; ++s) {
+    __builtin_amdgcn_sched_barrier(0);
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[s % DEPTH], b0[s], acc0, 0, 0, 0);
+    if (s + DEPTH < NKS) a0[s % DEPTH] = la.row(img0, s + DEPTH);
+    __builtin_amdgcn_sched_barrier(0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s % DEPTH], b1[s], acc1, 0, 0, 0);
+    if (s + DEPTH < NKS) a1[s % DEPTH] = la.row(img1, s + DEPTH);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // DMA one 32-row image (rows row0.. of a [*, ld] bf16 matrix seen through rs) into lds_img.
 // 4 waves, each issues 32/RPI/4 wave-instructions of 1 KiB.
 template <int HDP>
@@ -111,6 +133,9 @@ __device__ __forceinline__ void dma_tile(__amdgpu_buffer_rsrc_t rs, int row0, in
     const int cphys = lane % C::CPR;
     const int clog = cphys ^ xr(row);
     const uint32_t voff = (uint32_t)(((int64_t)(row0 + row) * ld) * 2 + clog * 16);
+#ifdef ATT_EXP_NO_DMA
+    if (row0 > 0) continue;
+#endif
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds_img + piece * 1024), 16, voff, 0, 0, 0);
   }
 }
@@ -320,10 +345,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
 #pragma unroll
       for (int k = 0; k < 4; ++k) { sacc[4 * rr + k] = -l4[k] * inv_scale; dpacc[4 * rr + k] = -d4[k]; }
     }
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.row(qimg, s), kf[s], sacc, 0, 0, 0);
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.row(doimg, s), vf[s], dpacc, 0, 0, 0);
+    dual_chain<HDP, NKS, 2>(sacc, dpacc, qimg, doimg, la, kf, vf);
     float p[16], ds[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { p[r] = fast_exp2(sacc[r] * c_exp2); ds[r] = p[r] * dpacc[r]; }
@@ -417,10 +439,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
     f32x16 sacc, dpacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sacc[r] = s_init; dpacc[r] = d_init; }
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.row(kimg, s), qf[s], sacc, 0, 0, 0);
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) dpacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.row(vimg, s), dof[s], dpacc, 0, 0, 0);
+    dual_chain<HDP, NKS, 3>(sacc, dpacc, kimg, vimg, la, qf, dof);
     float ds[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(sacc[r] * c_exp2) * dpacc[r];
