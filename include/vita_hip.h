@@ -172,7 +172,7 @@ int vita_attn_supported(int64_t hd, int64_t hdp);
 int vita_attn_fwd(const void* qkv, void* o, float* lse, int64_t B, int64_t N, int64_t H, int64_t hd,
                   int64_t hdp, float scale, void* stream);
 /* backward: recomputes P from q, k and lse; deterministic (no atomics).  dout bf16 [B][N][H][hdp];
- * delta fp32 [B][H][N] scratch (rowsum(dout*o), written here); dqkv bf16 like qkv, every element of
+ * delta fp32 [B][H][2][N] scratch (written here: a copy of lse and rowsum(dout*o)); dqkv bf16 like qkv, every element of
  * the three parts is written (pads zero). */
 int vita_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta,
                   void* dqkv, int64_t B, int64_t N, int64_t H, int64_t hd, int64_t hdp, float scale,

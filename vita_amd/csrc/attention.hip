@@ -86,6 +86,12 @@ struct LdsAddr {
 #pragma unroll
     for (int j = 0; j < NTB; ++j) { tb[j][0] ^= bytes; tb[j][1] ^= bytes; }
   }
+  __device__ __forceinline__ void advance(int bytes) {  // move to another ring slot (wave-uniform delta)
+#pragma unroll
+    for (int j = 0; j < NRB; ++j) rb[j] += bytes;
+#pragma unroll
+    for (int j = 0; j < NTB; ++j) { tb[j][0] += bytes; tb[j][1] += bytes; }
+  }
   __device__ __forceinline__ bf16x8 row(const char* img, int s) const {
     return *reinterpret_cast<const bf16x8*>(img + rb[s & 7] + 256 * (s >> 3));
   }
@@ -119,6 +125,21 @@ __device__ __forceinline__ void dual_chain(f32x16& acc0, f32x16& acc1, const cha
   __builtin_amdgcn_sched_barrier(0);
 }
 
+
+template <int HDP, int NKS, int DEPTH>
+__device__ __forceinline__ void single_chain(f32x16& acc, const char* img, const LdsAddr<HDP, NKS>& la, const bf16x8 (&b)[NKS]) {
+  bf16x8 a[DEPTH];
+#pragma unroll
+  for (int j = 0; j < DEPTH && j < NKS; ++j) a[j] = la.row(img, j);
+#pragma unroll
+  for (int s = 0; s < NKS; ++s) {
+    __builtin_amdgcn_sched_barrier(0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % DEPTH], b[s], acc, 0, 0, 0);
+    if (s + DEPTH < NKS) a[s % DEPTH] = la.row(img, s + DEPTH);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // DMA one 32-row image (rows row0.. of a [*, ld] bf16 matrix seen through rs) into lds_img.
 // 4 waves, each issues 32/RPI/4 wave-instructions of 1 KiB.
 template <int HDP>
@@ -140,6 +161,15 @@ __device__ __forceinline__ void dma_tile(__amdgpu_buffer_rsrc_t rs, int row0, in
   }
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// wait until at most N of this wave's youngest vector-memory operations are still in flight
+template <int N> __device__ __forceinline__ void dma_wait_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// barrier that does not drain the LDS-DMA queue (a __syncthreads() would add vmcnt(0))
+__device__ __forceinline__ void ring_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+#define ATT_NSLOT 3
 
 template <int HDP>
 __device__ __forceinline__ void lds_zero(char* smem, int bytes, int tid) {
@@ -198,8 +228,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
     f32x16 sacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.row(kimg, s), qf[s], sacc, 0, 0, 0);
+    single_chain<HDP, NKS, 4>(sacc, kimg, la, qf);
     if (kbase + 32 > N) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)
@@ -253,8 +282,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
 }
 
 // ============================================================================================ backward
+// ld2[b][h][0][q] = lse, ld2[b][h][1][q] = delta = rowsum(dO * O): one buffer so that a single resource
+// descriptor serves the per-tile 4-byte LDS-DMA of both
 __global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restrict__ o, const uint16_t* __restrict__ dout,
-                                                         float* __restrict__ delta, int64_t BN, int N, int H, int HDP) {
+                                                         const float* __restrict__ lse, float* __restrict__ ld2, int64_t BN, int N,
+                                                         int H, int HDP) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // row in [0, B*N)
   if (row >= BN) return;
@@ -271,7 +303,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restr
       acc += bf16_bits_to_f32((uint16_t)(a[1] >> 16)) * bf16_bits_to_f32((uint16_t)(d[1] >> 16));
     }
     acc = wave_sum(acc);
-    if (lane == 0) delta[(b * H + h) * N + q] = acc;
+    if (lane == 0) {
+      ld2[((b * H + h) * 2 + 1) * N + q] = acc;
+      ld2[((b * H + h) * 2) * N + q] = lse[(b * H + h) * N + q];
+    }
   }
 }
 
@@ -281,7 +316,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
                                                                uint16_t* __restrict__ dqkv, int N, int H, float scale) {
   using C = AttCfg<HDP>;
   constexpr int RS = C::RS, NDT = C::NDT, TILE = C::TILE;
-  constexpr int BUF = 2 * TILE;                   // ring slot = [ Q image | dO image ]; lse/delta[2][64] after the ring
+  constexpr int BUF = 2 * TILE;                   // ring slot = [ Q image | dO image ]; lse/delta[NSLOT][64] after the ring
+  constexpr int NSLOT = ATT_NSLOT, DPT = 2 * (32 / C::RPI / 4);   // DMA instructions per wave per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.y, b = blockIdx.z;
@@ -293,10 +329,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
   const __amdgpu_buffer_rsrc_t rsK = mk_rsrc(base + (H + h) * HDP, extent);
   const __amdgpu_buffer_rsrc_t rsV = mk_rsrc(base + (2 * H + h) * HDP, extent);
   const __amdgpu_buffer_rsrc_t rsDO = mk_rsrc(dout + (int64_t)b * N * ldo + h * HDP, extent_o);
-  const float* lse_bh = lse + ((int64_t)b * H + h) * N;
-  const float* delta_bh = delta + ((int64_t)b * H + h) * N;
+  const __amdgpu_buffer_rsrc_t rsL = mk_rsrc(delta + ((int64_t)b * H + h) * 2 * N, (uint32_t)N * 8);   // [lse | delta]
+  const bool wave0 = __builtin_amdgcn_readfirstlane(wave) == 0;
 
-  lds_zero<HDP>(smem, 2 * BUF + 512, tid);
+  lds_zero<HDP>(smem, NSLOT * BUF + NSLOT * 256, tid);
   const int lk = lane & 31, hh = lane >> 5;
   const int key = blockIdx.x * 128 + wave * 32 + lk;
   bf16x8 kf[NKS], vf[NKS];
@@ -319,24 +355,34 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
     char* bp = smem + buf * BUF;
     dma_tile<HDP>(rsQ, tile * 32, ld, bp, wave, lane);
     dma_tile<HDP>(rsDO, tile * 32, ldo, bp + TILE, wave, lane);
-    if (tid < 64) {
-      const int qq = tile * 32 + (tid & 31);
-      const float v = qq < N ? (tid < 32 ? lse_bh[qq] : delta_bh[qq]) : 0.f;
-      reinterpret_cast<float*>(smem + 2 * BUF + buf * 256)[tid] = v;
+    if (wave0) {   // lse[32] | delta[32] of the tile, 4-byte LDS-DMA (rows past N come back as zeros)
+      typedef __attribute__((address_space(3))) void lds_void;
+      lds_void* dst = (lds_void*)(smem + NSLOT * BUF + buf * 256);
+      const int qq = tile * 32 + (lane & 31);
+      // rows past N: the lse half then reads delta values (finite; masked below), the delta half reads zeros
+      const uint32_t voff = (uint32_t)((lane < 32 ? qq : (qq < N ? N + qq : 2 * N))) * 4;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL, dst, 4, voff, 0, 0, 0);
     }
+  };
+  auto wait_tiles_in_flight = [&](bool one) {   // leave `one` tile's DMAs of this wave outstanding
+    if (!one) dma_wait();
+    else if (wave0) dma_wait_n<DPT + 1>();
+    else dma_wait_n<DPT>();
   };
   LdsAddr<HDP, NKS> la;
   la.init(lane);
   __syncthreads();
   issue(0, 0);
-  dma_wait();
-  __syncthreads();
+  if (ntiles > 1) issue(1, 1);
+  wait_tiles_in_flight(ntiles > 1);
+  ring_barrier();
+  int slot = 0;
   for (int tile = 0; tile < ntiles; ++tile) {
-    const int cur = tile & 1;
-    if (tile + 1 < ntiles) issue(tile + 1, cur ^ 1);
+    const int cur = slot;
+    const int pre = slot >= 1 ? slot - 1 : NSLOT - 1;   // (slot + 2) % 3
     const char* qimg = smem;
     const char* doimg = smem + TILE;
-    const float* ls = reinterpret_cast<const float*>(smem + 2 * BUF + cur * 256);
+    const float* ls = reinterpret_cast<const float*>(smem + NSLOT * BUF + cur * 256);
     f32x16 sacc, dpacc;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -362,9 +408,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
       dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(doimg, i, 1), pf1, dv[i], 0, 0, 0);
       dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(qimg, i, 1), df1, dk[i], 0, 0, 0);
     }
-    la.toggle(BUF);
-    dma_wait();
-    __syncthreads();
+    // prefetch two tiles ahead; issued after this tile's last LDS read because hipcc drains the DMA queue
+    // (vmcnt(0)) in front of the transposed reads
+    if (tile + 2 < ntiles) issue(tile + 2, pre);
+    slot = slot + 1 == NSLOT ? 0 : slot + 1;
+    la.advance(slot == 0 ? -(NSLOT - 1) * BUF : BUF);
+    wait_tiles_in_flight(tile + 2 < ntiles);
+    ring_barrier();
   }
   if (key < N) {
     uint16_t* krow = dqkv + ((int64_t)b * N + key) * ld + (H + h) * HDP;
@@ -387,7 +437,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
                                                              uint16_t* __restrict__ dqkv, int N, int H, float scale) {
   using C = AttCfg<HDP>;
-  constexpr int RS = C::RS, NDT = C::NDT, TILE = C::TILE, BUF = 2 * TILE;   // [ K image | V image ]
+  constexpr int RS = C::RS, NDT = C::NDT, TILE = C::TILE, BUF = 2 * TILE;   // ring slot = [ K image | V image ]
+  constexpr int NSLOT = ATT_NSLOT, DPT = 2 * (32 / C::RPI / 4);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.y, b = blockIdx.z;
@@ -400,7 +451,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
   const __amdgpu_buffer_rsrc_t rsV = mk_rsrc(base + (2 * H + h) * HDP, extent);
   const __amdgpu_buffer_rsrc_t rsDO = mk_rsrc(dout + (int64_t)b * N * ldo + h * HDP, extent_o);
 
-  lds_zero<HDP>(smem, 2 * BUF, tid);
+  lds_zero<HDP>(smem, NSLOT * BUF, tid);
   const int lq = lane & 31, hh = lane >> 5;
   const int q = blockIdx.x * 128 + wave * 32 + lq;
   bf16x8 qf[NKS], dof[NKS];
@@ -410,8 +461,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
     dof[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsDO, (uint32_t)(((int64_t)q * ldo + 16 * s + 8 * hh) * 2), 0, 0));
   }
   const float c_exp2 = scale * 1.4426950408889634f;
-  const float s_init = q < N ? -lse[((int64_t)b * H + h) * N + q] / scale : 0.f;
-  const float d_init = q < N ? -delta[((int64_t)b * H + h) * N + q] : 0.f;
+  const float s_init = q < N ? -delta[(((int64_t)b * H + h) * 2) * N + q] / scale : 0.f;        // delta = [lse | delta]
+  const float d_init = q < N ? -delta[(((int64_t)b * H + h) * 2 + 1) * N + q] : 0.f;
   f32x16 dq[NDT];
 #pragma unroll
   for (int i = 0; i < NDT; ++i)
@@ -422,17 +473,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
 
   LdsAddr<HDP, NKS> la;
   la.init(lane);
+  auto issue = [&](int tile, int buf) {
+    dma_tile<HDP>(rsK, tile * 32, ld, smem + buf * BUF, wave, lane);
+    dma_tile<HDP>(rsV, tile * 32, ld, smem + buf * BUF + TILE, wave, lane);
+  };
   __syncthreads();
-  dma_tile<HDP>(rsK, 0, ld, smem, wave, lane);
-  dma_tile<HDP>(rsV, 0, ld, smem + TILE, wave, lane);
-  dma_wait();
-  __syncthreads();
+  issue(0, 0);
+  if (ntiles > 1) { issue(1, 1); dma_wait_n<DPT>(); } else dma_wait();
+  ring_barrier();
+  int slot = 0;
   for (int tile = 0; tile < ntiles; ++tile) {
-    const int cur = tile & 1;
-    if (tile + 1 < ntiles) {
-      dma_tile<HDP>(rsK, (tile + 1) * 32, ld, smem + (cur ^ 1) * BUF, wave, lane);
-      dma_tile<HDP>(rsV, (tile + 1) * 32, ld, smem + (cur ^ 1) * BUF + TILE, wave, lane);
-    }
+    const int pre = slot >= 1 ? slot - 1 : NSLOT - 1;
     const char* kimg = smem;
     const char* vimg = smem + TILE;
     const int kbase = tile * 32;
@@ -454,9 +505,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
       dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(kimg, i, 0), df0, dq[i], 0, 0, 0);
       dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(kimg, i, 1), df1, dq[i], 0, 0, 0);
     }
-    la.toggle(BUF);
-    dma_wait();
-    __syncthreads();
+    if (tile + 2 < ntiles) issue(tile + 2, pre);
+    slot = slot + 1 == NSLOT ? 0 : slot + 1;
+    la.advance(slot == 0 ? -(NSLOT - 1) * BUF : BUF);
+    if (tile + 2 < ntiles) dma_wait_n<DPT>(); else dma_wait();
+    ring_barrier();
   }
   if (q < N) {
     uint16_t* qrow = dqkv + ((int64_t)b * N + q) * ld + h * HDP;
@@ -487,7 +540,7 @@ static int launch_fwd(const void* qkv, void* o, float* lse, int64_t B, int64_t N
 template <int HDP, int NKS>
 static int launch_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, int64_t B,
                       int64_t N, int64_t H, float scale, hipStream_t s) {
-  const size_t lds_kv = 4 * AttCfg<HDP>::TILE + 512, lds_q = 4 * AttCfg<HDP>::TILE;
+  const size_t lds_kv = ATT_NSLOT * (2 * AttCfg<HDP>::TILE + 256), lds_q = ATT_NSLOT * 2 * AttCfg<HDP>::TILE;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<HDP, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
@@ -495,7 +548,7 @@ static int launch_bwd(const void* qkv, const void* o, const void* dout, const fl
     attr = true;
   }
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((B * N + 3) / 4)), dim3(256), 0, s, (const uint16_t*)o, (const uint16_t*)dout,
-                     delta, B * N, (int)N, (int)H, HDP);
+                     lse, delta, B * N, (int)N, (int)H, HDP);
   VITA_CHECK_LAUNCH("vita_attn_bwd(delta)");
   dim3 grid((unsigned)((N + 127) / 128), (unsigned)H, (unsigned)B);
   hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDP, NKS>), grid, dim3(256), lds_kv, s, (const uint16_t*)qkv, (const uint16_t*)dout, lse,

@@ -250,7 +250,7 @@ def attn_fwd(qkv, o, lse, B, N, H, hd, hdp, scale):
 
 
 def attn_bwd(qkv, o, do, lse, dqkv, B, N, H, hd, hdp, scale):
-    delta = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
+    delta = torch.empty(B, H, 2, N, dtype=torch.float32, device=qkv.device)   # [lse | rowsum(dO*O)] scratch
     with _Timed("attn_bwd_kernels", 10.0 * B * H * N * N * hd):
         check(_lib.lib().vita_attn_bwd(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), delta.data_ptr(),
                                        dqkv.data_ptr(), B, N, H, hd, hdp, scale, _s()), "attn_bwd")
