@@ -142,10 +142,10 @@ __device__ __forceinline__ void single_chain(f32x16& acc, const char* img, const
 
 // DMA one 32-row image (rows row0.. of a [*, ld] bf16 matrix seen through rs) into lds_img.
 // 4 waves, each issues 32/RPI/4 wave-instructions of 1 KiB.
-template <int HDP>
+template <int HDP, int NW = 4>
 __device__ __forceinline__ void dma_tile(__amdgpu_buffer_rsrc_t rs, int row0, int64_t ld, char* lds_img, int wave, int lane) {
   using C = AttCfg<HDP>;
-  constexpr int NI = 32 / C::RPI / 4;
+  constexpr int NI = 32 / C::RPI / NW;
   typedef __attribute__((address_space(3))) void lds_void;
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
@@ -173,28 +173,30 @@ __device__ __forceinline__ void ring_barrier() {
 
 template <int HDP>
 __device__ __forceinline__ void lds_zero(char* smem, int bytes, int tid) {
-  for (int o = tid * 16; o < bytes; o += 256 * 16) *reinterpret_cast<u32x4*>(smem + o) = u32x4{0, 0, 0, 0};
+  for (int o = tid * 16; o < bytes; o += (int)blockDim.x * 16) *reinterpret_cast<u32x4*>(smem + o) = u32x4{0, 0, 0, 0};
 }
 
 // ============================================================================================ forward
-template <int HDP, int NKS>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ o,
-                                                          float* __restrict__ lse, int N, int H, float c_exp2) {
+template <int HDP, int NKS, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ o,
+                                                              float* __restrict__ lse, int N, int H, float c_exp2) {
   using C = AttCfg<HDP>;
-  constexpr int RS = C::RS, NDT = C::NDT, BUF = 2 * C::TILE;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][K image | V image]
+  constexpr int RS = C::RS, NDT = C::NDT, BUF = 2 * C::TILE, NSLOT = ATT_NSLOT;
+  constexpr int DPT = 2 * (32 / C::RPI / NW);                   // DMA instructions per wave per tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // ring of NSLOT x [K image | V image]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.y, b = blockIdx.z;
   const int64_t ld = 3ll * H * HDP;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (NW * 32) + wave * 32;
   const uint16_t* base = qkv + (int64_t)b * N * ld;
   const uint32_t extent = (uint32_t)((((int64_t)N - 1) * ld + HDP) * 2);
   const __amdgpu_buffer_rsrc_t rsQ = mk_rsrc(base + h * HDP, extent);
   const __amdgpu_buffer_rsrc_t rsK = mk_rsrc(base + (H + h) * HDP, extent);
   const __amdgpu_buffer_rsrc_t rsV = mk_rsrc(base + (2 * H + h) * HDP, extent);
 
-  lds_zero<HDP>(smem, 2 * BUF, tid);
+  lds_zero<HDP>(smem, NSLOT * BUF, tid);
   const int lq = lane & 31, hh = lane >> 5;
+  const bool active = __builtin_amdgcn_readfirstlane(q0) < N;     // waves past the last row only feed the ring
   bf16x8 qf[NKS];
 #pragma unroll
   for (int s = 0; s < NKS; ++s)
@@ -206,63 +208,67 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const uint16_t* __rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
-  const int gi = lane >> 4, t = lane & 15, tq = t >> 2, tp = t & 3;
 
   const int ntiles = (N + 31) / 32;
   LdsAddr<HDP, NKS> la;
   la.init(lane);
+  auto issue = [&](int tile, int buf) {
+    dma_tile<HDP, NW>(rsK, tile * 32, ld, smem + buf * BUF, wave, lane);
+    dma_tile<HDP, NW>(rsV, tile * 32, ld, smem + buf * BUF + C::TILE, wave, lane);
+  };
   __syncthreads();
-  dma_tile<HDP>(rsK, 0, ld, smem, wave, lane);
-  dma_tile<HDP>(rsV, 0, ld, smem + C::TILE, wave, lane);
-  dma_wait();
-  __syncthreads();
+  issue(0, 0);
+  if (ntiles > 1) { issue(1, 1); dma_wait_n<DPT>(); } else dma_wait();
+  ring_barrier();
+  int slot = 0;
   for (int kt = 0; kt < ntiles; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < ntiles) {
-      dma_tile<HDP>(rsK, (kt + 1) * 32, ld, smem + (cur ^ 1) * BUF, wave, lane);
-      dma_tile<HDP>(rsV, (kt + 1) * 32, ld, smem + (cur ^ 1) * BUF + C::TILE, wave, lane);
-    }
-    const char* kimg = smem;            // the ring position lives in the address bases (la.toggle)
+    const int pre = slot >= 1 ? slot - 1 : NSLOT - 1;
+    const char* kimg = smem;            // the ring position lives in the address bases (la.advance)
     const char* vimg = smem + C::TILE;
     const int kbase = kt * 32;
-    f32x16 sacc;
+    if (active) {
+      f32x16 sacc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-    single_chain<HDP, NKS, 4>(sacc, kimg, la, qf);
-    if (kbase + 32 > N) {
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+      single_chain<HDP, NKS, 4>(sacc, kimg, la, qf);
+      if (kbase + 32 > N) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (kbase + (r & 3) + 8 * (r >> 2) + 4 * hh >= N) sacc[r] = -INFINITY;
+        for (int r = 0; r < 16; ++r)
+          if (kbase + (r & 3) + 8 * (r >> 2) + 4 * hh >= N) sacc[r] = -INFINITY;
+      }
+      float mx = sacc[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float mc = m_new * c_exp2;
+      float p[16];
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { p[r] = fast_exp2(sacc[r] * c_exp2 - mc); rs += p[r]; }
+      if (__any(m_new > m_run)) {     // exact: the O rescale is skipped only when no row's max moved
+        const float alpha = fast_exp2((m_run - m_new) * c_exp2);
+        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < NDT; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        m_run = m_new;
+      }
+      l_run += rs;
+      const bf16x8 pf0 = pack8(p), pf1 = pack8(p + 8);
+#pragma unroll
+      for (int i = 0; i < NDT; ++i) {
+        oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(vimg, i, 0), pf0, oacc[i], 0, 0, 0);
+        oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(vimg, i, 1), pf1, oacc[i], 0, 0, 0);
+      }
     }
-    float mx = sacc[0];
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float mc = m_new * c_exp2;
-    float p[16];
-    float rs = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { p[r] = fast_exp2(sacc[r] * c_exp2 - mc); rs += p[r]; }
-    if (__any(m_new > m_run)) {     // exact: the O rescale is skipped only when no row's max moved
-      const float alpha = fast_exp2((m_run - m_new) * c_exp2);
-      l_run *= alpha;
-#pragma unroll
-      for (int i = 0; i < NDT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-      m_run = m_new;
-    }
-    l_run += rs;
-    const bf16x8 pf0 = pack8(p), pf1 = pack8(p + 8);
-#pragma unroll
-    for (int i = 0; i < NDT; ++i) {
-      oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(vimg, i, 0), pf0, oacc[i], 0, 0, 0);
-      oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(vimg, i, 1), pf1, oacc[i], 0, 0, 0);
-    }
-    la.toggle(BUF);
-    dma_wait();
-    __syncthreads();
+    // prefetch two tiles ahead, after this tile's last LDS read (hipcc drains vmcnt in front of tr reads)
+    if (kt + 2 < ntiles) issue(kt + 2, pre);
+    slot = slot + 1 == NSLOT ? 0 : slot + 1;
+    la.advance(slot == 0 ? -(NSLOT - 1) * BUF : BUF);
+    if (kt + 2 < ntiles) dma_wait_n<DPT>(); else dma_wait();
+    ring_barrier();
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l_tot;
@@ -527,11 +533,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
 // ============================================================================================ host
 template <int HDP, int NKS>
 static int launch_fwd(const void* qkv, void* o, float* lse, int64_t B, int64_t N, int64_t H, float scale, hipStream_t s) {
-  const size_t lds = 4 * AttCfg<HDP>::TILE;
+  constexpr int NW = 8;
+  const size_t lds = ATT_NSLOT * 2 * AttCfg<HDP>::TILE;
   static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HDP, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  dim3 grid((unsigned)((N + 127) / 128), (unsigned)H, (unsigned)B);
-  hipLaunchKernelGGL((attn_fwd_kernel<HDP, NKS>), grid, dim3(256), lds, s, (const uint16_t*)qkv, (uint16_t*)o, lse, (int)N, (int)H,
+  if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HDP, NKS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  dim3 grid((unsigned)((N + NW * 32 - 1) / (NW * 32)), (unsigned)H, (unsigned)B);
+  hipLaunchKernelGGL((attn_fwd_kernel<HDP, NKS, NW>), grid, dim3(NW * 64), lds, s, (const uint16_t*)qkv, (uint16_t*)o, lse, (int)N, (int)H,
                      scale * 1.4426950408889634f);
   VITA_CHECK_LAUNCH("vita_attn_fwd");
   return VITA_OK;
