@@ -13,6 +13,36 @@ from . import ops
 from .nn import _require_cuda
 
 
+def gather_towers(a: torch.Tensor, b: torch.Tensor, group):
+    """All-gather both towers' [B_local, d] embeddings in ONE message -> ([B_global, d], [B_global, d]);
+    rank r's rows land at [r*B_local, (r+1)*B_local).  Device-agnostic (RCCL on GPU, gloo in CPU tests)."""
+    world = dist.get_world_size(group)
+    Bl, d = a.shape
+    packed = torch.stack([a, b]).contiguous()
+    gathered = torch.empty(world, 2, Bl, d, dtype=a.dtype, device=a.device)
+    if hasattr(dist, "all_gather_into_tensor") and dist.get_backend(group) != "gloo":
+        dist.all_gather_into_tensor(gathered, packed, group=group)
+    else:
+        parts = list(gathered.unbind(0))
+        dist.all_gather(parts, packed, group=group)
+    return (gathered[:, 0].reshape(world * Bl, d).contiguous(), gathered[:, 1].reshape(world * Bl, d).contiguous())
+
+
+def scatter_tower_grads(cross: torch.Tensor, group):
+    """Backward of gather_towers: cross [2, B_global, d] holds this rank's gradient w.r.t. every rank's
+    embeddings; returns the sum over ranks of the slice that belongs to this rank, [2, B_local, d]."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    _, Bg, d = cross.shape
+    Bl = Bg // world
+    send = cross.view(2, world, Bl, d).permute(1, 0, 2, 3).contiguous()
+    if dist.get_backend(group) != "gloo":
+        recv = torch.empty(2, Bl, d, dtype=cross.dtype, device=cross.device)
+        dist.reduce_scatter_tensor(recv, send, group=group)
+        return recv
+    dist.all_reduce(send, group=group)     # gloo has no reduce-scatter
+    return send[rank].contiguous()
+
+
 class _ClipFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, out0, out1, tau, lam0, group, grad_world_scale):
@@ -22,11 +52,7 @@ class _ClipFn(torch.autograd.Function):
         b, ib = ops.l2_normalize_fwd(out1)
         world, rank = (dist.get_world_size(group), dist.get_rank(group)) if group is not None else (1, 0)
         if world > 1:
-            packed = torch.stack([a, b])                                  # one message for both towers
-            gathered = torch.empty(world, 2, Bl, d, dtype=torch.float32, device=a.device)
-            dist.all_gather_into_tensor(gathered, packed, group=group)
-            a_all = gathered[:, 0].reshape(world * Bl, d).contiguous()
-            b_all = gathered[:, 1].reshape(world * Bl, d).contiguous()
+            a_all, b_all = gather_towers(a, b, group)
         else:
             a_all, b_all = a, b
         Bg, off = world * Bl, rank * Bl
@@ -61,9 +87,7 @@ class _ClipFn(torch.autograd.Function):
             cross = torch.empty(2, Bg, d, dtype=torch.float32, device=dev)
             ops.sgemm(d_ti, b, cross[0], Bg, d, Bl, Bg, d, d, 1, 1, alpha=1.0 / tau)
             ops.sgemm(d_it, a, cross[1], Bg, d, Bl, Bg, d, d, 1, 1, alpha=1.0 / tau)
-            send = cross.view(2, world, Bl, d).permute(1, 0, 2, 3).contiguous()
-            recv = torch.empty(2, Bl, d, dtype=torch.float32, device=dev)
-            dist.reduce_scatter_tensor(recv, send, group=group)          # backward of the all-gather
+            recv = scatter_tower_grads(cross, group)                      # backward of the all-gather
             da += recv[0]; db += recv[1]
         else:
             ops.sgemm(d_ti, b, da, Bg, d, Bl, Bg, d, d, 1, 1, alpha=1.0 / tau, beta=1.0)

@@ -86,7 +86,8 @@ class BucketedAllReduce:
     def __init__(self, opt: FlatAdam, group=None, bucket_mb=48):
         self.opt, self.group = opt, group
         self.world = dist.get_world_size(group)
-        self.stream = torch.cuda.Stream()
+        self.cuda = opt.g.is_cuda
+        self.stream = torch.cuda.Stream() if self.cuda else None
         cap = bucket_mb * (1 << 20) // 4
         self.buckets = []           # (start, end, n_params)
         self.bucket_of = {}
@@ -98,6 +99,7 @@ class BucketedAllReduce:
                 self.buckets.append((lo, hi, cnt)); hi = lo; cnt = 0
         self.pending = [0] * len(self.buckets)
         self.handles = []
+        self.launch_order = []
         for i, p in enumerate(opt.params):
             p.register_post_accumulate_grad_hook(self._make_hook(i))
 
@@ -111,6 +113,10 @@ class BucketedAllReduce:
 
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
+        self.launch_order.append(b)
+        if not self.cuda:      # gloo / CPU rehearsal of the same bucketing and hook logic
+            self.handles.append(dist.all_reduce(self.opt.g[lo:hi], group=self.group, async_op=True))
+            return
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
             self.handles.append(dist.all_reduce(self.opt.g[lo:hi], group=self.group, async_op=True))
@@ -122,7 +128,8 @@ class BucketedAllReduce:
                 self._launch(b)
         for h in self.handles:
             h.wait()
-        torch.cuda.current_stream().wait_stream(self.stream)
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.stream)
         self.handles = []
         self.pending = [0] * len(self.buckets)
 
