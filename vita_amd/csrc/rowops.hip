@@ -79,14 +79,15 @@ extern "C" int64_t vita_layernorm_bwd_nblk(int64_t rows) {
 // registers across the rows a wave owns and are reduced over the block's 4 waves through LDS.
 template <int NV>
 __global__ __launch_bounds__(256, 2) void ln_bwd_kernel(const void* __restrict__ dy, int64_t lddy, int dy_f32,
-                                                     const float* __restrict__ x, int64_t ldx,
-                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, const float* __restrict__ dx_in,
-                                                     float* __restrict__ dx_out, int64_t lddx, uint16_t* __restrict__ dxb,
-                                                     int64_t ld_dxb, float* __restrict__ partial, int64_t rows, int d) {
+                                                        const float* __restrict__ x, int64_t ldx,
+                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, const float* __restrict__ dx_in,
+                                                        float* __restrict__ dx_out, int64_t lddx, uint16_t* __restrict__ dxb,
+                                                        int64_t ld_dxb, float* __restrict__ partial, int64_t rows, int d) {
   __shared__ float red[2][NV * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nblk = gridDim.x;
+  // per-lane column masks: msk[i][r] = 1 for real columns, 0 for pad columns (only the last chunk is mixed)
   f32x4 g[NV], ag[NV], ab[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_kernel(const void* __restrict__
 #pragma unroll
     for (int r = 0; r < 4; ++r) if (c + r < d) g[i][r] = gamma[c + r];
   }
+  const float inv_d = 1.f / (float)d;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)nblk * 4) {
     const float mu = mean[row], rs = rstd[row];
     f32x4 xh[NV], dyv[NV];
@@ -108,31 +110,36 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_kernel(const void* __restrict__
         if (dy_f32) dyv[i] = *reinterpret_cast<const f32x4*>((const float*)dy + row * lddy + c);
         else {
           const u32x2 u = *reinterpret_cast<const u32x2*>((const uint16_t*)dy + row * lddy + c);
-          dyv[i] = f32x4{bf16_bits_to_f32((uint16_t)(u[0] & 0xffff)), bf16_bits_to_f32((uint16_t)(u[0] >> 16)),
-                         bf16_bits_to_f32((uint16_t)(u[1] & 0xffff)), bf16_bits_to_f32((uint16_t)(u[1] >> 16))};
+          dyv[i] = f32x4{__builtin_bit_cast(float, u[0] << 16), __builtin_bit_cast(float, u[0] & 0xffff0000u),
+                         __builtin_bit_cast(float, u[1] << 16), __builtin_bit_cast(float, u[1] & 0xffff0000u)};
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (c + r < d) {
-            xh[i][r] = (xv[r] - mu) * rs;
-            const float t = dyv[i][r] * g[i][r];
-            s1 += t; s2 += t * xh[i][r];
-            ag[i][r] += dyv[i][r] * xh[i][r];
-            ab[i][r] += dyv[i][r];
-          } else { dyv[i][r] = 0.f; }
-        }
+        // pad columns: gamma is 0 there, so s1/s2 ignore them; dy pads are masked for dgamma/dbeta below
+        xh[i] = (xv - mu) * rs;
+        const f32x4 t = dyv[i] * g[i];
+        s1 += t[0] + t[1] + t[2] + t[3];
+        const f32x4 tx = t * xh[i];
+        s2 += tx[0] + tx[1] + tx[2] + tx[3];
       }
     }
-    const float c1 = wave_sum(s1) / (float)d, c2 = wave_sum(s2) / (float)d;
+    const float c1 = wave_sum(s1) * inv_d, c2 = wave_sum(s2) * inv_d;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
       if (c >= lddx) continue;
       f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
       if (c < d) {
-        if (dx_in) o = *reinterpret_cast<const f32x4*>(dx_in + row * lddx + c);
+        if (c + 4 > d) {   // mixed chunk: zero the pad lanes of dy so that dbeta / dx pads stay exact zeros
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (c + r < d) ? o[r] + rs * (dyv[i][r] * g[i][r] - c1 - xh[i][r] * c2) : 0.f;
+          for (int r = 0; r < 4; ++r) if (c + r >= d) { dyv[i][r] = 0.f; xh[i][r] = 0.f; }
+        }
+        ag[i] += dyv[i] * xh[i];
+        ab[i] += dyv[i];
+        o = (dyv[i] * g[i] - c1 - xh[i] * c2) * rs;
+        if (c + 4 > d) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (c + r >= d) o[r] = 0.f;
+        }
+        if (dx_in) o += *reinterpret_cast<const f32x4*>(dx_in + row * lddx + c);
       }
       *reinterpret_cast<f32x4*>(dx_out + row * lddx + c) = o;
       if (dxb && c < ld_dxb)
@@ -191,6 +198,7 @@ extern "C" int vita_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype
   if (width <= 256) LN_BWD_LAUNCH(1);
   else if (width <= 512) LN_BWD_LAUNCH(2);
   else if (width <= 1280) LN_BWD_LAUNCH(5);
+  else if (width <= 1536) LN_BWD_LAUNCH(6);
   else LN_BWD_LAUNCH(8);
 #undef LN_BWD_LAUNCH
   VITA_CHECK_LAUNCH("vita_layernorm_bwd");
