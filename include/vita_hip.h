@@ -72,6 +72,9 @@ typedef struct vita_gemm_desc {
 } vita_gemm_desc;
 
 int vita_gemm_bf16(const vita_gemm_desc* d, void* stream);
+/* Same, with the kernel chosen by the caller (tests, tuning): variant 0 = by shape, 1 = 128x128x64
+ * tile kernel, 13 / 14 / 16 = 256 x (16*variant) x 64 LDS-DMA kernel (un-batched problems only). */
+int vita_gemm_bf16_ex(const vita_gemm_desc* d, int32_t variant, void* stream);
 
 /* ------------------------------------------------------------------ weight shadows
  * fp32 logical [rows_log][cols_log] -> bf16 physical [rows_phys][ld_phys] with the same

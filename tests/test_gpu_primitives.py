@@ -322,3 +322,89 @@ def test_flash_attention_bwd(ops, B, N, H, hd):
         g, r = got[:, :, i, :, :hd], leaf.grad[:, :, i, :, :hd]
         err = ((g - r).norm() / r.norm()).item()
         assert err < 2e-2, (name, err)
+
+
+# ---------------------------------------------------------------- large-tile (256 x 16*NF) LDS-DMA GEMM
+def _mk_operand(M, free, k, layout, ld_pad=0):
+    """logical [free, k] matrix -> storage for the given layout, padded leading dim, garbage-free pads."""
+    r8 = lambda x: (x + 7) // 8 * 8
+    if layout == 0:
+        ld = r8(k) + ld_pad
+        t = torch.zeros(free, ld, dtype=torch.bfloat16); t[:, :k] = M
+    else:
+        ld = r8(free) + ld_pad
+        t = torch.randn(k, ld).to(torch.bfloat16); t[:, :free] = M.t()
+    return t, ld
+
+
+@pytest.mark.parametrize("variant", [13, 14, 16])
+@pytest.mark.parametrize("la,lb", [(0, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("m,n,k", [(256, 224, 64), (700, 1088, 1120), (1000, 420, 200), (513, 3360, 1088), (2500, 1040, 4112)])
+def test_gemm256_layouts(ops, variant, la, lb, m, n, k):
+    torch.manual_seed(m + n + k + la * 2 + lb + variant)
+    A = bf(torch.randn(m, k)); B = bf(torch.randn(n, k))
+    ref = A.float() @ B.float().t()
+    a, lda = _mk_operand(A, m, k, la, ld_pad=8 if la == 0 else 0)
+    b, ldb = _mk_operand(B, n, k, lb, ld_pad=16 if lb == 1 else 0)
+    ldc = n + 8
+    c = torch.full((m, ldc), float("nan"), device="cuda")
+    ops.gemm(dev(a), dev(b), c, m, n, k, lda, ldb, ldc, a_layout=la, b_layout=lb, variant=variant)
+    torch.cuda.synchronize()
+    out = c.cpu()
+    assert torch.isnan(out[:, n:]).all()               # nothing written past n
+    assert _rel(out[:, :n], ref) < 1e-5
+    torch.testing.assert_close(out[:, :n], ref, rtol=1e-3, atol=2e-2)
+
+
+@pytest.mark.parametrize("variant", [13, 14])
+def test_gemm256_epilogues(ops, variant):
+    torch.manual_seed(variant)
+    m, n, k = 777, 1120, 456
+    A = bf(torch.randn(m, k)); W = bf(torch.randn(n, k) * 0.05); bias = torch.randn(n)
+    pre = A.float() @ W.float().t() + bias
+    c = torch.empty(m, n, dtype=torch.bfloat16, device="cuda"); u = torch.empty_like(c)
+    ops.gemm(dev(A), dev(W), c, m, n, k, k, k, n, bias=dev(bias), epilogue=ops.EPI_GELU, aux_out=u, variant=variant)
+    torch.testing.assert_close(u.cpu().float(), pre, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(c.cpu().float(), torch.nn.functional.gelu(pre), rtol=2e-2, atol=2e-2)
+    res = torch.randn(m, n)
+    c2 = torch.empty(m, n, device="cuda")
+    ops.gemm(dev(A), dev(W), c2, m, n, k, k, k, n, bias=dev(bias), epilogue=ops.EPI_RESIDUAL, aux_in=dev(res), ld_aux=n,
+             variant=variant)
+    torch.testing.assert_close(c2.cpu(), pre + res, rtol=1e-3, atol=2e-3)
+    uu = bf(torch.randn(m, n))
+    c3 = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+    Wt = W.t().contiguous()      # [K][N] for the k-strided B path (dgrad layout)
+    ops.gemm(dev(A), dev(Wt), c3, m, n, k, k, n, n, b_layout=1, epilogue=ops.EPI_GELU_BWD, aux_in=dev(uu), ld_aux=n,
+             variant=variant)
+    x = uu.float().requires_grad_(True); torch.nn.functional.gelu(x).sum().backward()
+    torch.testing.assert_close(c3.cpu().float(), (A.float() @ W.float().t()) * x.grad, rtol=2e-2, atol=2e-2)
+    # alpha + bf16 out on the asymmetric-identity check
+    mm = 512
+    eye = torch.eye(mm).to(torch.bfloat16)
+    Bm = ((torch.arange(mm)[:, None] * 3 + torch.arange(448)[None, :]) % 61).float()
+    c5 = torch.empty(mm, 448, device="cuda")
+    ops.gemm(dev(eye), dev(Bm.t().contiguous().to(torch.bfloat16)), c5, mm, 448, mm, mm, mm, 448, alpha=2.0, variant=variant)
+    assert torch.equal(c5.cpu(), 2.0 * Bm)
+
+
+@pytest.mark.parametrize("variant", [13, 14, 16])
+@pytest.mark.parametrize("split_k", [1, 3])
+def test_gemm256_wgrad_maps(ops, variant, split_k):
+    """weight-gradient form: dW = dY^T X with head-padded rows un-padded through the segment maps."""
+    torch.manual_seed(5 + variant + split_k)
+    tokens, n_out_phys, k_in_phys = 1500, 3 * 96, 528          # rows: 3 segments of 96 with 77 real; cols: 520 real
+    seg_phys, seg_log, k_in = 96, 77, 520
+    dY = bf(torch.randn(tokens, n_out_phys)); X = bf(torch.randn(tokens, k_in_phys))
+    full = dY.float().t() @ X.float()
+    keep = [r for r in range(n_out_phys) if r % seg_phys < seg_log]
+    ref = full[keep][:, :k_in]
+    out = torch.zeros(len(keep), k_in, device="cuda")
+    ops.gemm(dev(dY), dev(X), out, n_out_phys, k_in, tokens, n_out_phys, k_in_phys, k_in, a_layout=1, b_layout=1,
+             split_k=split_k, row_seg=(seg_phys, seg_log), variant=variant)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-3, atol=2e-2)
+    # column map (proj.weight: K_in is head padded)
+    keepc = [c for c in range(k_in_phys) if c % 88 < 80]
+    out2 = torch.zeros(n_out_phys, len(keepc), device="cuda")
+    ops.gemm(dev(dY), dev(X), out2, n_out_phys, k_in_phys, tokens, n_out_phys, k_in_phys, len(keepc), a_layout=1, b_layout=1,
+             split_k=split_k, col_seg=(88, 80), variant=variant)
+    torch.testing.assert_close(out2.cpu(), full[:, keepc], rtol=1e-3, atol=2e-2)

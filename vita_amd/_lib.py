@@ -34,6 +34,7 @@ class GemmDesc(C.Structure):
 SIGNATURES = {
     "vita_version": [],
     "vita_gemm_bf16": [C.POINTER(GemmDesc), vp],
+    "vita_gemm_bf16_ex": [C.POINTER(GemmDesc), i32, vp],
     "vita_pack_weight_bf16": [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, vp],
     "vita_pack_vec_f32": [vp, i64, vp, i64, i32, i32, vp],
     "vita_unpack_vec_f32": [vp, i64, vp, i64, i32, i32, vp],

@@ -244,7 +244,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams P) {
   }
 }
 
-extern "C" int vita_gemm_bf16(const vita_gemm_desc* dp, void* stream) {
+// gemm256.hip
+bool vita_gemm256_supported(const vita_gemm_desc& d);
+double vita_gemm256_cost(const vita_gemm_desc& d, int* nf_out);
+double vita_gemm128_cost(const vita_gemm_desc& d);
+int vita_gemm256_launch(const vita_gemm_desc& d, int nf, hipStream_t s);
+
+// variant: 0 = choose by shape, 1 = 128x128 kernel, 13 / 14 / 16 = 256 x (16*variant) kernel
+extern "C" int vita_gemm_bf16_ex(const vita_gemm_desc* dp, int32_t variant, void* stream) {
   if (!dp) return VITA_ERR_INVALID_ARG;
   vita_gemm_desc d = *dp;
   VITA_REQUIRE(d.a && d.b && d.c);
@@ -276,6 +283,18 @@ extern "C" int vita_gemm_bf16(const vita_gemm_desc* dp, void* stream) {
   const int64_t a_rows = d.a_layout == 0 ? BM : d.k, b_rows = d.b_layout == 0 ? BN : d.k;
   VITA_REQUIRE(a_rows * d.lda * 2 < (int64_t)0xffffffffll && b_rows * d.ldb * 2 < (int64_t)0xffffffffll);
 
+  if (variant != 1) {
+    const bool ok = vita_gemm256_supported(d);
+    if (variant > 1) {
+      VITA_REQUIRE(ok && (variant == 13 || variant == 14 || variant == 16));
+      return vita_gemm256_launch(d, variant, (hipStream_t)stream);
+    }
+    // large un-batched problems: whichever kernel needs fewer (weighted) rounds of workgroups
+    if (ok && d.m >= 512 && d.n >= 208 && d.k >= 256) {
+      int nf = 0;
+      if (vita_gemm256_cost(d, &nf) <= vita_gemm128_cost(d)) return vita_gemm256_launch(d, nf, (hipStream_t)stream);
+    }
+  }
   GemmParams P;
   P.d = d;
   P.tiles_m = (int)((d.m + BM - 1) / BM);
@@ -303,3 +322,5 @@ extern "C" int vita_gemm_bf16(const vita_gemm_desc* dp, void* stream) {
   VITA_CHECK_LAUNCH("vita_gemm_bf16");
   return VITA_OK;
 }
+
+extern "C" int vita_gemm_bf16(const vita_gemm_desc* dp, void* stream) { return vita_gemm_bf16_ex(dp, 0, stream); }

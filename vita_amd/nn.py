@@ -139,10 +139,11 @@ def attention_bwd(do, qkv, o, saved, B, N, dm: Dims):
 
 
 def _split_k_for(m, n, k):
-    tiles = ((m + 127) // 128) * ((n + 127) // 128)
+    """split-K factor for a weight gradient (K = tokens): fill the 256 CUs with 256-row tiles, keep at least 4
+    K-tiles per split, and cap the atomic traffic (split x output bytes)."""
+    tiles = ((m + 255) // 256) * ((n + 223) // 224)
     kt = (k + 63) // 64
-    s = max(1, min(8, (2 * 256 + tiles - 1) // tiles, kt // 4 if kt >= 4 else 1))
-    return s
+    return max(1, min(8, 256 // tiles if tiles <= 256 else 1, kt // 4 if kt >= 4 else 1))
 
 
 def wgrad(dy, lddy, x, ldx, rows_out, cols_out, k_tokens, row_seg=(0, 0), col_seg=(0, 0), m_phys=None, n_phys=None):

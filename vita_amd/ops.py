@@ -55,7 +55,7 @@ class _Timed:
 def gemm(a, b, c, m, n, k, lda, ldb, ldc, *, a_layout=0, b_layout=0, bias=None, epilogue=EPI_NONE,
          aux_in=None, aux_out=None, ld_aux=0, alpha=1.0, split_k=1, batch=(1, 1),
          a_strides=(0, 0), b_strides=(0, 0), c_strides=(0, 0), row_seg=(0, 0), col_seg=(0, 0),
-         a_off=0, b_off=0, c_off=0, flops=None):
+         a_off=0, b_off=0, c_off=0, flops=None, variant=0):
     """C[m,n] = epi(alpha * A(m,k) B(k,n)); a/b bf16 tensors, c bf16|fp32.  *_off are element offsets.
     flops: algorithmic (un-padded) FLOPs of this launch for the roofline accounting."""
     assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
@@ -76,7 +76,7 @@ def gemm(a, b, c, m, n, k, lda, ldb, ldc, *, a_layout=0, b_layout=0, bias=None, 
     d.col_seg_phys, d.col_seg_log = col_seg
     d.alpha = alpha
     with _Timed(f"gemm_kernel<{a_layout},{b_layout}>", flops if flops is not None else 2.0 * m * n * k * batch[0] * batch[1]):
-        check(_lib.lib().vita_gemm_bf16(C.byref(d), _s()), "vita_gemm_bf16")
+        check(_lib.lib().vita_gemm_bf16_ex(C.byref(d), variant, _s()), "vita_gemm_bf16")
     return c
 
 
