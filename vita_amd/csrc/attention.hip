@@ -288,7 +288,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const uint16_t* __
 }
 
 // ============================================================================================ backward
-// ld2[b][h][0][q] = lse, ld2[b][h][1][q] = delta = rowsum(dO * O): one buffer so that a single resource
+// ld2[b][h][0][q] = -lse * log2(e), ld2[b][h][1][q] = delta = rowsum(dO * O): one buffer so that a single resource
 // descriptor serves the per-tile 4-byte LDS-DMA of both
 __global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restrict__ o, const uint16_t* __restrict__ dout,
                                                          const float* __restrict__ lse, float* __restrict__ ld2, int64_t BN, int N,
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restr
     acc = wave_sum(acc);
     if (lane == 0) {
       ld2[((b * H + h) * 2 + 1) * N + q] = acc;
-      ld2[((b * H + h) * 2) * N + q] = lse[(b * H + h) * N + q];
+      ld2[((b * H + h) * 2) * N + q] = lse[(b * H + h) * N + q] * -1.4426950408889634f;   // -lse * log2(e)
     }
   }
 }
@@ -389,18 +389,23 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
     const char* qimg = smem;
     const char* doimg = smem + TILE;
     const float* ls = reinterpret_cast<const float*>(smem + NSLOT * BUF + cur * 256);
+    // S and dP start from zero (the C operand is then an inline constant: no VGPR -> AGPR copies in front
+    // of the chains); the row constants -lse*log2(e) and delta are applied in the exponent / the product
     f32x16 sacc, dpacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+    dual_chain<HDP, NKS, 2>(sacc, dpacc, qimg, doimg, la, kf, vf);
+    float p[16], ds[16];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const f32x4 l4 = *reinterpret_cast<const f32x4*>(ls + 8 * rr + 4 * hh);
       const f32x4 d4 = *reinterpret_cast<const f32x4*>(ls + 32 + 8 * rr + 4 * hh);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { sacc[4 * rr + k] = -l4[k] * inv_scale; dpacc[4 * rr + k] = -d4[k]; }
+      for (int k = 0; k < 4; ++k) {
+        p[4 * rr + k] = fast_exp2(__builtin_fmaf(sacc[4 * rr + k], c_exp2, l4[k]));
+        ds[4 * rr + k] = p[4 * rr + k] * (dpacc[4 * rr + k] - d4[k]);
+      }
     }
-    dual_chain<HDP, NKS, 2>(sacc, dpacc, qimg, doimg, la, kf, vf);
-    float p[16], ds[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { p[r] = fast_exp2(sacc[r] * c_exp2); ds[r] = p[r] * dpacc[r]; }
     if (tile * 32 + 32 > N) {       // query rows past N: force exact zeros whatever the LDS holds
 #pragma unroll
       for (int r = 0; r < 16; ++r)
@@ -467,8 +472,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
     dof[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsDO, (uint32_t)(((int64_t)q * ldo + 16 * s + 8 * hh) * 2), 0, 0));
   }
   const float c_exp2 = scale * 1.4426950408889634f;
-  const float s_init = q < N ? -delta[(((int64_t)b * H + h) * 2) * N + q] / scale : 0.f;        // delta = [lse | delta]
-  const float d_init = q < N ? -delta[(((int64_t)b * H + h) * 2 + 1) * N + q] : 0.f;
+  const float nl2 = q < N ? delta[(((int64_t)b * H + h) * 2) * N + q] : 0.f;        // delta = [-lse*log2(e) | delta]
+  const float dlt = q < N ? delta[(((int64_t)b * H + h) * 2 + 1) * N + q] : 0.f;
   f32x16 dq[NDT];
 #pragma unroll
   for (int i = 0; i < NDT; ++i)
@@ -495,11 +500,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
     const int kbase = tile * 32;
     f32x16 sacc, dpacc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { sacc[r] = s_init; dpacc[r] = d_init; }
+    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
     dual_chain<HDP, NKS, 3>(sacc, dpacc, kimg, vimg, la, qf, dof);
     float ds[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(sacc[r] * c_exp2) * dpacc[r];
+    for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(__builtin_fmaf(sacc[r], c_exp2, nl2)) * (dpacc[r] - dlt);
     if (kbase + 32 > N) {
 #pragma unroll
       for (int r = 0; r < 16; ++r)

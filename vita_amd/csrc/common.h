@@ -36,11 +36,30 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// Exact-erf GELU (nn.GELU() default, timm Mlp) evaluated with the Abramowitz-Stegun 7.1.26 rational
+// approximation of erf (|abs error| <= 1.5e-7, far below the bf16 resolution of the tensors it feeds):
+//   Phi(x) = 1 - 0.5 * poly(t) * exp(-x^2/2),  t = 1 / (1 + p |x| / sqrt(2))      (x >= 0; mirrored for x < 0)
+// ~14 VALU instructions instead of libdevice erff's ~60; exp(-x^2/2) is shared with the density in the gradient.
+__device__ __forceinline__ float gelu_half_tail(float x, float& e) {   // returns 0.5 * poly(t) * exp(-x^2/2) = Phi(-|x|)
+  const float ax = __builtin_fabsf(x);
+  e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);            // exp(-x^2/2)
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(ax, 0.23164189f, 1.0f));   // p / sqrt(2) = 0.3275911 * 0.70710678
+  float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+  poly = __builtin_fmaf(t, poly, 1.421413741f);
+  poly = __builtin_fmaf(t, poly, -0.284496736f);
+  poly = __builtin_fmaf(t, poly, 0.254829592f);
+  return 0.5f * poly * t * e;
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+  float e;
+  const float tail = gelu_half_tail(x, e);
+  return x * (x >= 0.f ? 1.0f - tail : tail);
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float e;
+  const float tail = gelu_half_tail(x, e);
+  const float cdf = x >= 0.f ? 1.0f - tail : tail;
+  return __builtin_fmaf(x * 0.3989422804014327f, e, cdf);
 }
 
 // physical -> logical index through a segment map (0 = identity); returns -1 when dropped
