@@ -23,6 +23,7 @@
 // Backward is deterministic (no atomics) at the price of recomputing S and dP in both kernels.
 #include "common.h"
 #include <type_traits>
+#include <utility>
 
 template <int HDP> struct AttCfg {
   static constexpr int RS = (HDP * 2 <= 256) ? 256 : 512;   // LDS row stride in bytes
@@ -98,7 +99,38 @@ struct LdsAddr {
   __device__ __forceinline__ bf16x8 tr(const char* img, int i, int s2) const {
     return tr_pair(img, tb[i & 3][0] + 256 * (i >> 2) + (16 * s2) * RS, tb[i & 3][1] + 256 * (i >> 2) + (16 * s2 + 8) * RS);
   }
+  // The same read as inline asm (IMG = byte offset of the image inside a ring slot; dynamic LDS starts at
+  // LDS address 0 in these kernels).  hipcc puts s_waitcnt vmcnt(0) in front of the ds_read_b64_tr_b16
+  // builtin whenever an LDS-DMA is in flight; the asm form is invisible to that pass, so the caller waits
+  // for the data with a counted lgkmcnt (tr_wait) followed by a sched_barrier.
+  template <int I, int S2, int IMG>
+  __device__ __forceinline__ bf16x8 tr_asm() const {
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v2i lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(tb[I & 3][0]), "n"(IMG + 256 * (I >> 2) + (16 * S2) * RS) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(tb[I & 3][1]), "n"(IMG + 256 * (I >> 2) + (16 * S2 + 8) * RS) : "memory");
+    v4i v = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, v);
+  }
 };
+// wait until at most N LDS operations of this wave are outstanding, and keep the MFMAs that consume
+// asm-read fragments behind the wait
+template <int N> __device__ __forceinline__ void tr_wait() {
+  __builtin_amdgcn_s_waitcnt(0xc07f | (N << 8));
+  __builtin_amdgcn_sched_barrier(0);
+}
+// an empty asm that uses every accumulator tile as an AGPR operand
+template <int N> __device__ __forceinline__ void pin_agpr(f32x16 (&acc)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+a"(acc[i]));
+}
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* p, uint32_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
@@ -107,9 +139,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* p, uint32_
 // Two independent row-read -> MFMA accumulation chains (S and dP), software pipelined DEPTH k-steps
 // ahead so the ds_read_b128 latency is covered by the other chain's MFMAs; the order is pinned with
 // sched_barrier because hipcc otherwise serialises read -> wait -> MFMA when registers are tight.
-template <int HDP, int NKS, int DEPTH>
+template <int HDP, int NKS, int DEPTH, class F>
 __device__ __forceinline__ void dual_chain(f32x16& acc0, f32x16& acc1, const char* img0, const char* img1,
-                                           const LdsAddr<HDP, NKS>& la, const bf16x8 (&b0)[NKS], const bf16x8 (&b1)[NKS]) {
+                                           const LdsAddr<HDP, NKS>& la, const bf16x8 (&b0)[NKS], const bf16x8 (&b1)[NKS],
+                                           F&& between) {
   bf16x8 a0[DEPTH], a1[DEPTH];
 #pragma unroll
   for (int j = 0; j < DEPTH && j < NKS; ++j) { a0[j] = la.row(img0, j); a1[j] = la.row(img1, j); }
@@ -121,6 +154,7 @@ __device__ __forceinline__ void dual_chain(f32x16& acc0, f32x16& acc1, const cha
     __builtin_amdgcn_sched_barrier(0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[s % DEPTH], b1[s], acc1, 0, 0, 0);
     if (s + DEPTH < NKS) a1[s % DEPTH] = la.row(img1, s + DEPTH);
+    between(s);     // e.g. one LDS-DMA piece of a later tile: its issue time hides under the two MFMAs
   }
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -141,24 +175,24 @@ __device__ __forceinline__ void single_chain(f32x16& acc, const char* img, const
 }
 
 // DMA one 32-row image (rows row0.. of a [*, ld] bf16 matrix seen through rs) into lds_img.
-// 4 waves, each issues 32/RPI/4 wave-instructions of 1 KiB.
+// NW waves, each issues NI = 32/RPI/NW wave-instructions ("pieces") of 1 KiB; dma_piece issues piece j.
 template <int HDP, int NW = 4>
-__device__ __forceinline__ void dma_tile(__amdgpu_buffer_rsrc_t rs, int row0, int64_t ld, char* lds_img, int wave, int lane) {
+__device__ __forceinline__ void dma_piece(__amdgpu_buffer_rsrc_t rs, int row0, int64_t ld, char* lds_img, int wave, int lane, int j) {
   using C = AttCfg<HDP>;
   constexpr int NI = 32 / C::RPI / NW;
   typedef __attribute__((address_space(3))) void lds_void;
+  const int piece = wave * NI + j;
+  const int row = piece * C::RPI + lane / C::CPR;
+  const int cphys = lane % C::CPR;
+  const int clog = cphys ^ xr(row);
+  const uint32_t voff = (uint32_t)(((int64_t)(row0 + row) * ld) * 2 + clog * 16);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds_img + piece * 1024), 16, voff, 0, 0, 0);
+}
+template <int HDP, int NW = 4>
+__device__ __forceinline__ void dma_tile(__amdgpu_buffer_rsrc_t rs, int row0, int64_t ld, char* lds_img, int wave, int lane) {
+  constexpr int NI = 32 / AttCfg<HDP>::RPI / NW;
 #pragma unroll
-  for (int j = 0; j < NI; ++j) {
-    const int piece = wave * NI + j;
-    const int row = piece * C::RPI + lane / C::CPR;
-    const int cphys = lane % C::CPR;
-    const int clog = cphys ^ xr(row);
-    const uint32_t voff = (uint32_t)(((int64_t)(row0 + row) * ld) * 2 + clog * 16);
-#ifdef ATT_EXP_NO_DMA
-    if (row0 > 0) continue;
-#endif
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds_img + piece * 1024), 16, voff, 0, 0, 0);
-  }
+  for (int j = 0; j < NI; ++j) dma_piece<HDP, NW>(rs, row0, ld, lds_img, wave, lane, j);
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // wait until at most N of this wave's youngest vector-memory operations are still in flight
@@ -357,11 +391,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
   const int gi = lane >> 4, t = lane & 15, tq = t >> 2, tp = t & 3;
   const int ntiles = (N + 31) / 32;
 
-  auto issue = [&](int tile, int buf) {
+  constexpr int NI = 32 / C::RPI / 4;             // DMA pieces per wave per image
+  // piece p of the tile's prefetch: [0,NI) Q image, [NI,2NI) dO image, 2NI = lse | delta (wave 0 only)
+  auto issue_piece = [&](int tile, int buf, int p) {
     char* bp = smem + buf * BUF;
-    dma_tile<HDP>(rsQ, tile * 32, ld, bp, wave, lane);
-    dma_tile<HDP>(rsDO, tile * 32, ldo, bp + TILE, wave, lane);
-    if (wave0) {   // lse[32] | delta[32] of the tile, 4-byte LDS-DMA (rows past N come back as zeros)
+    if (p < NI) dma_piece<HDP>(rsQ, tile * 32, ld, bp, wave, lane, p);
+    else if (p < 2 * NI) dma_piece<HDP>(rsDO, tile * 32, ldo, bp + TILE, wave, lane, p - NI);
+    else if (wave0) {   // lse[32] | delta[32] of the tile, 4-byte LDS-DMA (rows past N come back as zeros)
       typedef __attribute__((address_space(3))) void lds_void;
       lds_void* dst = (lds_void*)(smem + NSLOT * BUF + buf * 256);
       const int qq = tile * 32 + (lane & 31);
@@ -369,6 +405,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
       const uint32_t voff = (uint32_t)((lane < 32 ? qq : (qq < N ? N + qq : 2 * N))) * 4;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL, dst, 4, voff, 0, 0, 0);
     }
+  };
+  auto issue = [&](int tile, int buf) {
+#pragma unroll
+    for (int p = 0; p <= 2 * NI; ++p) issue_piece(tile, buf, p);
   };
   auto wait_tiles_in_flight = [&](bool one) {   // leave `one` tile's DMAs of this wave outstanding
     if (!one) dma_wait();
@@ -394,7 +434,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
     f32x16 sacc, dpacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
-    dual_chain<HDP, NKS, 2>(sacc, dpacc, qimg, doimg, la, kf, vf);
+    // the DMA of tile+2 (into the slot tile-1 used; tiles past the end read zeros) is issued piece by piece
+    // between the MFMAs of the S / dP chains, where its issue time is hidden
+    dual_chain<HDP, NKS, 2>(sacc, dpacc, qimg, doimg, la, kf, vf, [&](int s) {
+      if (s == 0 || s == NKS - 1) { pin_agpr(dk); pin_agpr(dv); }   // see attn_bwd_dq_kernel
+#pragma unroll
+      for (int p = s; p <= 2 * NI; p += NKS) issue_piece(tile + 2, pre, p);
+    });
     float p[16], ds[16];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -412,21 +458,33 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
         if (tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= N) { p[r] = 0.f; ds[r] = 0.f; }
     }
     const bf16x8 pf0 = pack8(p), pf1 = pack8(p + 8), df0 = pack8(ds), df1 = pack8(ds + 8);
-#pragma unroll
-    for (int i = 0; i < NDT; ++i) {
-      dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(doimg, i, 0), pf0, dv[i], 0, 0, 0);
-      dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(qimg, i, 0), df0, dk[i], 0, 0, 0);
-      dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(doimg, i, 1), pf1, dv[i], 0, 0, 0);
-      dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(qimg, i, 1), df1, dk[i], 0, 0, 0);
+    // transposed fragments by asm reads (no DMA drain), one d-tile ahead of the MFMAs that use them
+    {
+      bf16x8 fr[2][4];
+      fr[0][0] = la.template tr_asm<0, 0, TILE>(); fr[0][1] = la.template tr_asm<0, 0, 0>();
+      fr[0][2] = la.template tr_asm<0, 1, TILE>(); fr[0][3] = la.template tr_asm<0, 1, 0>();
+      static_for<NDT>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i + 1 < NDT) {
+          fr[(i + 1) & 1][0] = la.template tr_asm<i + 1, 0, TILE>(); fr[(i + 1) & 1][1] = la.template tr_asm<i + 1, 0, 0>();
+          fr[(i + 1) & 1][2] = la.template tr_asm<i + 1, 1, TILE>(); fr[(i + 1) & 1][3] = la.template tr_asm<i + 1, 1, 0>();
+          tr_wait<8>();
+        } else {
+          tr_wait<0>();
+        }
+        dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 1][0], pf0, dv[i], 0, 0, 0);
+        dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 1][1], df0, dk[i], 0, 0, 0);
+        dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 1][2], pf1, dv[i], 0, 0, 0);
+        dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 1][3], df1, dk[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      });
     }
-    // prefetch two tiles ahead; issued after this tile's last LDS read because hipcc drains the DMA queue
-    // (vmcnt(0)) in front of the transposed reads
-    if (tile + 2 < ntiles) issue(tile + 2, pre);
     slot = slot + 1 == NSLOT ? 0 : slot + 1;
     la.advance(slot == 0 ? -(NSLOT - 1) * BUF : BUF);
-    wait_tiles_in_flight(tile + 2 < ntiles);
+    wait_tiles_in_flight(true);
     ring_barrier();
   }
+  dma_wait();      // the zero-filled prefetches past the last tile must land before the LDS is released
   if (key < N) {
     uint16_t* krow = dqkv + ((int64_t)b * N + key) * ld + (H + h) * HDP;
     uint16_t* vrow = dqkv + ((int64_t)b * N + key) * ld + (2 * H + h) * HDP;
@@ -501,7 +559,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
     f32x16 sacc, dpacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
-    dual_chain<HDP, NKS, 3>(sacc, dpacc, kimg, vimg, la, qf, dof);
+    dual_chain<HDP, NKS, 3>(sacc, dpacc, kimg, vimg, la, qf, dof, [&](int s) {
+      constexpr int NI = 32 / C::RPI / 4;
+      // keep the dQ accumulators in their own AGPRs while the S / dP chains run: without this use the
+      // register allocator lets the chains share a[0:31] with dq[0..1] and copies 2 x 32 registers per tile
+      if (s == 0 || s == NKS - 1) pin_agpr(dq);
+#pragma unroll
+      for (int p = s; p < 2 * NI; p += NKS) {
+        if (p < NI) dma_piece<HDP>(rsK, (tile + 2) * 32, ld, smem + pre * BUF, wave, lane, p);
+        else dma_piece<HDP>(rsV, (tile + 2) * 32, ld, smem + pre * BUF + TILE, wave, lane, p - NI);
+      }
+    });
     float ds[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(__builtin_fmaf(sacc[r], c_exp2, nl2)) * (dpacc[r] - dlt);
@@ -511,17 +579,31 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
         if (kbase + (r & 3) + 8 * (r >> 2) + 4 * hh >= N) ds[r] = 0.f;
     }
     const bf16x8 df0 = pack8(ds), df1 = pack8(ds + 8);
-#pragma unroll
-    for (int i = 0; i < NDT; ++i) {
-      dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(kimg, i, 0), df0, dq[i], 0, 0, 0);
-      dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(kimg, i, 1), df1, dq[i], 0, 0, 0);
+    {
+      bf16x8 fr[3][2];      // two d-tiles ahead (only two MFMAs per d-tile here)
+      fr[0][0] = la.template tr_asm<0, 0, 0>(); fr[0][1] = la.template tr_asm<0, 1, 0>();
+      if constexpr (NDT > 1) { fr[1][0] = la.template tr_asm<1, 0, 0>(); fr[1][1] = la.template tr_asm<1, 1, 0>(); }
+      static_for<NDT>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i + 2 < NDT) {
+          fr[(i + 2) % 3][0] = la.template tr_asm<i + 2, 0, 0>(); fr[(i + 2) % 3][1] = la.template tr_asm<i + 2, 1, 0>();
+          tr_wait<8>();
+        } else if constexpr (i + 1 < NDT) {
+          tr_wait<4>();
+        } else {
+          tr_wait<0>();
+        }
+        dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % 3][0], df0, dq[i], 0, 0, 0);
+        dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % 3][1], df1, dq[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      });
     }
-    if (tile + 2 < ntiles) issue(tile + 2, pre);
     slot = slot + 1 == NSLOT ? 0 : slot + 1;
     la.advance(slot == 0 ? -(NSLOT - 1) * BUF : BUF);
-    if (tile + 2 < ntiles) dma_wait_n<DPT>(); else dma_wait();
+    dma_wait_n<DPT>();
     ring_barrier();
   }
+  dma_wait();      // zero-filled prefetches past the last tile
   if (q < N) {
     uint16_t* qrow = dqkv + ((int64_t)b * N + q) * ld + h * HDP;
 #pragma unroll
