@@ -87,12 +87,15 @@ struct LdsAddr {
 #pragma unroll
     for (int j = 0; j < NTB; ++j) { tb[j][0] ^= bytes; tb[j][1] ^= bytes; }
   }
-  __device__ __forceinline__ void advance(int bytes) {  // move to another ring slot (wave-uniform delta)
+  __device__ __forceinline__ void advance_rows(int bytes) {   // row-read bases to another ring slot
 #pragma unroll
     for (int j = 0; j < NRB; ++j) rb[j] += bytes;
+  }
+  __device__ __forceinline__ void advance_tr(int bytes) {     // transposed-read bases to another ring slot
 #pragma unroll
     for (int j = 0; j < NTB; ++j) { tb[j][0] += bytes; tb[j][1] += bytes; }
   }
+  __device__ __forceinline__ void advance(int bytes) { advance_rows(bytes); advance_tr(bytes); }
   __device__ __forceinline__ bf16x8 row(const char* img, int s) const {
     return *reinterpret_cast<const bf16x8*>(img + rb[s & 7] + 256 * (s >> 3));
   }
@@ -194,6 +197,28 @@ __device__ __forceinline__ void dma_tile(__amdgpu_buffer_rsrc_t rs, int row0, in
 #pragma unroll
   for (int j = 0; j < NI; ++j) dma_piece<HDP, NW>(rs, row0, ld, lds_img, wave, lane, j);
 }
+// Per-lane source offsets of a wave's NI pieces of a 32-row image, computed once; a tile is then
+// base offset (wave-uniform) + vb[j]: one VALU add per piece instead of the 64-bit address arithmetic.
+template <int HDP, int NW = 4>
+struct DmaOff {
+  static constexpr int NI = 32 / AttCfg<HDP>::RPI / NW;
+  uint32_t vb[NI];
+  __device__ __forceinline__ void init(int64_t ld, int wave, int lane) {
+    using C = AttCfg<HDP>;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int piece = wave * NI + j;
+      const int row = piece * C::RPI + lane / C::CPR;
+      const int clog = (lane % C::CPR) ^ xr(row);
+      vb[j] = (uint32_t)(row * ld * 2 + clog * 16);
+    }
+  }
+  // tile_off = byte offset of the tile's first row (wave-uniform)
+  __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, uint32_t tile_off, char* lds_img, int wave, int j) const {
+    typedef __attribute__((address_space(3))) void lds_void;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(lds_img + (wave * NI + j) * 1024), 16, vb[j] + tile_off, 0, 0, 0);
+  }
+};
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // wait until at most N of this wave's youngest vector-memory operations are still in flight
 template <int N> __device__ __forceinline__ void dma_wait_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -204,6 +229,7 @@ __device__ __forceinline__ void ring_barrier() {
   asm volatile("" ::: "memory");
 }
 #define ATT_NSLOT 3
+#define ATT_BWD_NSLOT 4   // the software-pipelined dK/dV kernel keeps tiles t .. t+3 in the ring
 
 template <int HDP>
 __device__ __forceinline__ void lds_zero(char* smem, int bytes, int tid) {
@@ -357,9 +383,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
   using C = AttCfg<HDP>;
   constexpr int RS = C::RS, NDT = C::NDT, TILE = C::TILE;
   constexpr int BUF = 2 * TILE;                   // ring slot = [ Q image | dO image ]; lse/delta[NSLOT][64] after the ring
-  constexpr int NSLOT = ATT_NSLOT, DPT = 2 * (32 / C::RPI / 4);   // DMA instructions per wave per tile
+  constexpr int NSLOT = ATT_BWD_NSLOT, DPT = 2 * (32 / C::RPI / 4);   // DMA instructions per wave per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = blockIdx.y, b = blockIdx.z;
   const int64_t ld = 3ll * H * HDP, ldo = (int64_t)H * HDP;
   const uint16_t* base = qkv + (int64_t)b * N * ld;
@@ -392,17 +418,22 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
   const int ntiles = (N + 31) / 32;
 
   constexpr int NI = 32 / C::RPI / 4;             // DMA pieces per wave per image
-  // piece p of the tile's prefetch: [0,NI) Q image, [NI,2NI) dO image, 2NI = lse | delta (wave 0 only)
+  DmaOff<HDP> offq, offo;
+  offq.init(ld, wave, lane);
+  offo.init(ldo, wave, lane);
+  // piece p of a tile's prefetch: [0,NI) Q image, [NI,2NI) dO image, 2NI = -lse*log2(e) | delta (wave 0 only).
+  // Tiles past the end are clamped to row ntiles*32 >= N: every row is then out of range and reads zeros.
   auto issue_piece = [&](int tile, int buf, int p) {
     char* bp = smem + buf * BUF;
-    if (p < NI) dma_piece<HDP>(rsQ, tile * 32, ld, bp, wave, lane, p);
-    else if (p < 2 * NI) dma_piece<HDP>(rsDO, tile * 32, ldo, bp + TILE, wave, lane, p - NI);
-    else if (wave0) {   // lse[32] | delta[32] of the tile, 4-byte LDS-DMA (rows past N come back as zeros)
+    const int tcl = tile < ntiles ? tile : ntiles;
+    if (p < NI) offq.issue(rsQ, (uint32_t)tcl * (uint32_t)(32 * ld * 2), bp, wave, p);
+    else if (p < 2 * NI) offo.issue(rsDO, (uint32_t)tcl * (uint32_t)(32 * ldo * 2), bp + TILE, wave, p - NI);
+    else if (wave0) {   // 4-byte LDS-DMA; rows past N read zeros in both halves (then p = 1 against a zero dO row
+                        // and ds = 0: no masking is needed in the loop)
       typedef __attribute__((address_space(3))) void lds_void;
       lds_void* dst = (lds_void*)(smem + NSLOT * BUF + buf * 256);
       const int qq = tile * 32 + (lane & 31);
-      // rows past N: the lse half then reads delta values (finite; masked below), the delta half reads zeros
-      const uint32_t voff = (uint32_t)((lane < 32 ? qq : (qq < N ? N + qq : 2 * N))) * 4;
+      const uint32_t voff = (uint32_t)(qq < N ? (lane < 32 ? qq : N + qq) : 2 * N) * 4;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL, dst, 4, voff, 0, 0, 0);
     }
   };
@@ -410,56 +441,82 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
 #pragma unroll
     for (int p = 0; p <= 2 * NI; ++p) issue_piece(tile, buf, p);
   };
-  auto wait_tiles_in_flight = [&](bool one) {   // leave `one` tile's DMAs of this wave outstanding
-    if (!one) dma_wait();
-    else if (wave0) dma_wait_n<DPT + 1>();
-    else dma_wait_n<DPT>();
+  auto wait_one_tile_in_flight = [&]() {   // leave the newest tile's DMAs of this wave outstanding
+    if (wave0) dma_wait_n<DPT + 1>(); else dma_wait_n<DPT>();
   };
   LdsAddr<HDP, NKS> la;
   la.init(lane);
   __syncthreads();
-  issue(0, 0);
-  if (ntiles > 1) issue(1, 1);
-  wait_tiles_in_flight(ntiles > 1);
+  issue(0, 0); issue(1, 1); issue(2, 2);
+  wait_one_tile_in_flight();      // tiles 0 and 1 have landed
   ring_barrier();
-  int slot = 0;
-  for (int tile = 0; tile < ntiles; ++tile) {
-    const int cur = slot;
-    const int pre = slot >= 1 ? slot - 1 : NSLOT - 1;   // (slot + 2) % 3
-    const char* qimg = smem;
-    const char* doimg = smem + TILE;
-    const float* ls = reinterpret_cast<const float*>(smem + NSLOT * BUF + cur * 256);
-    // S and dP start from zero (the C operand is then an inline constant: no VGPR -> AGPR copies in front
-    // of the chains); the row constants -lse*log2(e) and delta are applied in the exponent / the product
+
+  // Software pipeline over the query tiles, two phases per tile t:
+  //   A: MFMA chains S, dP of tile t+1 (zero C operand) | row reads, DMA of tile t+3, row constants of t+1
+  //   B: dV^T += dO^T P, dK^T += Q^T dS of tile t       | transposed reads, softmax algebra of tile t+1
+  // so the vector ALU work of one tile hides under the MFMAs of its neighbours.  Ring of 4 slots: tile t
+  // (transposed reads), t+1 (row reads), t+2 (landed or landing), t+3 (being issued).
+  // P and dS of the current tile live as packed bf16 words (pw / dw); rows past N give p = 1 against a zero
+  // dO row and ds = 0 (their row constants read as zeros), so no masking is needed.
+  uint32_t pw[8], dw[8];
+  auto softmax_elem = [&](int e, const f32x16& sacc, const f32x16& dpacc, const f32x4 (&l4)[4], const f32x4 (&d4)[4],
+                          float (&pe)[16], float (&de)[16], uint32_t (&pwn)[8], uint32_t (&dwn)[8]) {
+    const int rr = e >> 2, k = e & 3;
+    pe[e] = fast_exp2(__builtin_fmaf(sacc[e], c_exp2, l4[rr][k]));
+    de[e] = pe[e] * (dpacc[e] - d4[rr][k]);
+    if (e & 1) {
+      pwn[e >> 1] = cvt_pk(pe[e - 1], pe[e]); dwn[e >> 1] = cvt_pk(de[e - 1], de[e]);
+      // the words are consumed one tile later: without this use LLVM sinks the whole computation out from
+      // between the MFMAs to the top of the next iteration
+      asm volatile("" : "+v"(pwn[e >> 1]), "+v"(dwn[e >> 1]));
+    }
+  };
+  auto load_rowconst = [&](const float* ls, int rr, f32x4 (&l4)[4], f32x4 (&d4)[4]) {
+    l4[rr] = *reinterpret_cast<const f32x4*>(ls + 8 * rr + 4 * hh);
+    d4[rr] = *reinterpret_cast<const f32x4*>(ls + 32 + 8 * rr + 4 * hh);
+  };
+  {   // prologue: tile 0 without overlap
     f32x16 sacc, dpacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
-    // the DMA of tile+2 (into the slot tile-1 used; tiles past the end read zeros) is issued piece by piece
-    // between the MFMAs of the S / dP chains, where its issue time is hidden
-    dual_chain<HDP, NKS, 2>(sacc, dpacc, qimg, doimg, la, kf, vf, [&](int s) {
+    dual_chain<HDP, NKS, 2>(sacc, dpacc, smem, smem + TILE, la, kf, vf, [&](int s) {
+      if (s == 0 || s == NKS - 1) { pin_agpr(dk); pin_agpr(dv); }
+    });
+    f32x4 l4[4], d4[4];
+    float pe[16], de[16];
+    const float* ls = reinterpret_cast<const float*>(smem + NSLOT * BUF);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) load_rowconst(ls, rr, l4, d4);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) softmax_elem(e, sacc, dpacc, l4, d4, pe, de, pw, dw);
+  }
+  la.advance_rows(BUF);           // row reads now address tile 1's slot
+  int slot = 0;                   // slot of tile t
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int pre = slot >= 1 ? slot - 1 : NSLOT - 1;   // slot of tile t+3 = slot of tile t-1
+    const int nxt = slot + 1 == NSLOT ? 0 : slot + 1;   // slot of tile t+1
+    const float* lsn = reinterpret_cast<const float*>(smem + NSLOT * BUF + nxt * 256);
+    // ---- phase A
+    f32x16 sacc, dpacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+    f32x4 l4[4], d4[4];
+    dual_chain<HDP, NKS, 2>(sacc, dpacc, smem, smem + TILE, la, kf, vf, [&](int s) {
       if (s == 0 || s == NKS - 1) { pin_agpr(dk); pin_agpr(dv); }   // see attn_bwd_dq_kernel
 #pragma unroll
-      for (int p = s; p <= 2 * NI; p += NKS) issue_piece(tile + 2, pre, p);
+      for (int p = s; p <= 2 * NI; p += NKS) issue_piece(tile + 3, pre, p);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        if (s == (rr * NKS) / 4) load_rowconst(lsn, rr, l4, d4);
     });
-    float p[16], ds[16];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const f32x4 l4 = *reinterpret_cast<const f32x4*>(ls + 8 * rr + 4 * hh);
-      const f32x4 d4 = *reinterpret_cast<const f32x4*>(ls + 32 + 8 * rr + 4 * hh);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        p[4 * rr + k] = fast_exp2(__builtin_fmaf(sacc[4 * rr + k], c_exp2, l4[k]));
-        ds[4 * rr + k] = p[4 * rr + k] * (dpacc[4 * rr + k] - d4[k]);
-      }
-    }
-    if (tile * 32 + 32 > N) {       // query rows past N: force exact zeros whatever the LDS holds
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= N) { p[r] = 0.f; ds[r] = 0.f; }
-    }
-    const bf16x8 pf0 = pack8(p), pf1 = pack8(p + 8), df0 = pack8(ds), df1 = pack8(ds + 8);
-    // transposed fragments by asm reads (no DMA drain), one d-tile ahead of the MFMAs that use them
+    const bf16x8 pf0 = __builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]});
+    const bf16x8 pf1 = __builtin_bit_cast(bf16x8, u32x4{pw[4], pw[5], pw[6], pw[7]});
+    const bf16x8 df0 = __builtin_bit_cast(bf16x8, u32x4{dw[0], dw[1], dw[2], dw[3]});
+    const bf16x8 df1 = __builtin_bit_cast(bf16x8, u32x4{dw[4], dw[5], dw[6], dw[7]});
+    // ---- phase B: transposed fragments by asm reads (no DMA drain) one d-tile ahead of their MFMAs
     {
+      uint32_t pwn[8], dwn[8];
+      float pe[16], de[16];
       bf16x8 fr[2][4];
       fr[0][0] = la.template tr_asm<0, 0, TILE>(); fr[0][1] = la.template tr_asm<0, 0, 0>();
       fr[0][2] = la.template tr_asm<0, 1, TILE>(); fr[0][3] = la.template tr_asm<0, 1, 0>();
@@ -476,12 +533,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
         dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 1][1], df0, dk[i], 0, 0, 0);
         dv[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 1][2], pf1, dv[i], 0, 0, 0);
         dk[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 1][3], df1, dk[i], 0, 0, 0);
+        // softmax algebra of tile t+1, a slice per d-tile
+#pragma unroll
+        for (int e = (16 * i) / NDT; e < (16 * (i + 1)) / NDT; ++e) softmax_elem(e, sacc, dpacc, l4, d4, pe, de, pwn, dwn);
         __builtin_amdgcn_sched_barrier(0);
       });
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { pw[j] = pwn[j]; dw[j] = dwn[j]; }
     }
-    slot = slot + 1 == NSLOT ? 0 : slot + 1;
-    la.advance(slot == 0 ? -(NSLOT - 1) * BUF : BUF);
-    wait_tiles_in_flight(true);
+    slot = nxt;
+    la.advance_tr(slot == 0 ? -(NSLOT - 1) * BUF : BUF);
+    la.advance_rows(slot == NSLOT - 1 ? -(NSLOT - 1) * BUF : BUF);   // rows address slot+1
+    wait_one_tile_in_flight();    // tile t+2 has landed
     ring_barrier();
   }
   dma_wait();      // the zero-filled prefetches past the last tile must land before the LDS is released
@@ -507,9 +570,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
                                                              uint16_t* __restrict__ dqkv, int N, int H, float scale) {
   using C = AttCfg<HDP>;
   constexpr int RS = C::RS, NDT = C::NDT, TILE = C::TILE, BUF = 2 * TILE;   // ring slot = [ K image | V image ]
-  constexpr int NSLOT = ATT_NSLOT, DPT = 2 * (32 / C::RPI / 4);
+  constexpr int NSLOT = ATT_BWD_NSLOT, DPT = 2 * (32 / C::RPI / 4);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = blockIdx.y, b = blockIdx.z;
   const int64_t ld = 3ll * H * HDP, ldo = (int64_t)H * HDP;
   const uint16_t* base = qkv + (int64_t)b * N * ld;
@@ -542,44 +605,65 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
 
   LdsAddr<HDP, NKS> la;
   la.init(lane);
+  constexpr int NI = 32 / C::RPI / 4;
+  DmaOff<HDP> off;
+  off.init(ld, wave, lane);
+  // piece p of a tile's prefetch: [0,NI) K image, [NI,2NI) V image; tiles past the end read zeros
+  auto issue_piece = [&](int tile, int buf, int p) {
+    const int tcl = tile < ntiles ? tile : ntiles;
+    const uint32_t toff = (uint32_t)tcl * (uint32_t)(32 * ld * 2);
+    if (p < NI) off.issue(rsK, toff, smem + buf * BUF, wave, p);
+    else off.issue(rsV, toff, smem + buf * BUF + TILE, wave, p - NI);
+  };
   auto issue = [&](int tile, int buf) {
-    dma_tile<HDP>(rsK, tile * 32, ld, smem + buf * BUF, wave, lane);
-    dma_tile<HDP>(rsV, tile * 32, ld, smem + buf * BUF + TILE, wave, lane);
+#pragma unroll
+    for (int p = 0; p < 2 * NI; ++p) issue_piece(tile, buf, p);
   };
   __syncthreads();
-  issue(0, 0);
-  if (ntiles > 1) { issue(1, 1); dma_wait_n<DPT>(); } else dma_wait();
+  issue(0, 0); issue(1, 1); issue(2, 2);
+  dma_wait_n<DPT>();               // tiles 0 and 1 have landed
   ring_barrier();
-  int slot = 0;
-  for (int tile = 0; tile < ntiles; ++tile) {
-    const int pre = slot >= 1 ? slot - 1 : NSLOT - 1;
-    const char* kimg = smem;
-    const char* vimg = smem + TILE;
-    const int kbase = tile * 32;
+  // Software pipeline over the key tiles (see attn_bwd_dkdv_kernel): phase A = S / dP chains of tile t+1 with
+  // the DMA of tile t+3 between the MFMAs; phase B = dQ^T += K^T dS^T of tile t with the softmax algebra of
+  // tile t+1 between the MFMAs.  Keys past N have zero K rows, so their dS needs no masking.
+  uint32_t dw[8];
+  auto ds_elem = [&](int e, const f32x16& sacc, const f32x16& dpacc, float (&de)[16], uint32_t (&dwn)[8]) {
+    de[e] = fast_exp2(__builtin_fmaf(sacc[e], c_exp2, nl2)) * (dpacc[e] - dlt);
+    if (e & 1) {
+      dwn[e >> 1] = cvt_pk(de[e - 1], de[e]);
+      asm volatile("" : "+v"(dwn[e >> 1]));     // keeps the computation between the MFMAs (see the dK/dV kernel)
+    }
+  };
+  {
     f32x16 sacc, dpacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
-    dual_chain<HDP, NKS, 3>(sacc, dpacc, kimg, vimg, la, qf, dof, [&](int s) {
-      constexpr int NI = 32 / C::RPI / 4;
+    dual_chain<HDP, NKS, 3>(sacc, dpacc, smem, smem + TILE, la, qf, dof, [&](int s) {
+      if (s == 0 || s == NKS - 1) pin_agpr(dq);
+    });
+    float de[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ds_elem(e, sacc, dpacc, de, dw);
+  }
+  la.advance_rows(BUF);
+  int slot = 0;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int pre = slot >= 1 ? slot - 1 : NSLOT - 1;   // slot of tile t+3
+    f32x16 sacc, dpacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+    dual_chain<HDP, NKS, 3>(sacc, dpacc, smem, smem + TILE, la, qf, dof, [&](int s) {
       // keep the dQ accumulators in their own AGPRs while the S / dP chains run: without this use the
       // register allocator lets the chains share a[0:31] with dq[0..1] and copies 2 x 32 registers per tile
       if (s == 0 || s == NKS - 1) pin_agpr(dq);
 #pragma unroll
-      for (int p = s; p < 2 * NI; p += NKS) {
-        if (p < NI) dma_piece<HDP>(rsK, (tile + 2) * 32, ld, smem + pre * BUF, wave, lane, p);
-        else dma_piece<HDP>(rsV, (tile + 2) * 32, ld, smem + pre * BUF + TILE, wave, lane, p - NI);
-      }
+      for (int p = s; p < 2 * NI; p += NKS) issue_piece(tile + 3, pre, p);
     });
-    float ds[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ds[r] = fast_exp2(__builtin_fmaf(sacc[r], c_exp2, nl2)) * (dpacc[r] - dlt);
-    if (kbase + 32 > N) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (kbase + (r & 3) + 8 * (r >> 2) + 4 * hh >= N) ds[r] = 0.f;
-    }
-    const bf16x8 df0 = pack8(ds), df1 = pack8(ds + 8);
+    const bf16x8 df0 = __builtin_bit_cast(bf16x8, u32x4{dw[0], dw[1], dw[2], dw[3]});
+    const bf16x8 df1 = __builtin_bit_cast(bf16x8, u32x4{dw[4], dw[5], dw[6], dw[7]});
     {
+      uint32_t dwn[8];
+      float de[16];
       bf16x8 fr[3][2];      // two d-tiles ahead (only two MFMAs per d-tile here)
       fr[0][0] = la.template tr_asm<0, 0, 0>(); fr[0][1] = la.template tr_asm<0, 1, 0>();
       if constexpr (NDT > 1) { fr[1][0] = la.template tr_asm<1, 0, 0>(); fr[1][1] = la.template tr_asm<1, 1, 0>(); }
@@ -595,12 +679,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
         }
         dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % 3][0], df0, dq[i], 0, 0, 0);
         dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % 3][1], df1, dq[i], 0, 0, 0);
+#pragma unroll
+        for (int e = (16 * i) / NDT; e < (16 * (i + 1)) / NDT; ++e) ds_elem(e, sacc, dpacc, de, dwn);
         __builtin_amdgcn_sched_barrier(0);
       });
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dw[j] = dwn[j];
     }
     slot = slot + 1 == NSLOT ? 0 : slot + 1;
-    la.advance(slot == 0 ? -(NSLOT - 1) * BUF : BUF);
-    dma_wait_n<DPT>();
+    la.advance_tr(slot == 0 ? -(NSLOT - 1) * BUF : BUF);
+    la.advance_rows(slot == NSLOT - 1 ? -(NSLOT - 1) * BUF : BUF);
+    dma_wait_n<DPT>();            // tile t+2 has landed
     ring_barrier();
   }
   dma_wait();      // zero-filled prefetches past the last tile
@@ -616,6 +705,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
       }
   }
 }
+
+// Explicit instantiations: with the generic-lambda / if-constexpr bodies above hipcc (ROCm 7.2) silently skips the
+// host-side implicit instantiation of attn_bwd_dq_kernel from launch_bwd (undefined kernel handle at load time).
+#define ATT_INSTANTIATE_BWD(A, K)                                                                                      \
+  template __global__ void attn_bwd_dkdv_kernel<A, K>(const uint16_t*, const uint16_t*, const float*, const float*,  \
+                                                      uint16_t*, int, int, float);                                   \
+  template __global__ void attn_bwd_dq_kernel<A, K>(const uint16_t*, const uint16_t*, const float*, const float*,    \
+                                                    uint16_t*, int, int, float);
+ATT_INSTANTIATE_BWD(224, 13)
+ATT_INSTANTIATE_BWD(64, 3)
+ATT_INSTANTIATE_BWD(32, 2)
+ATT_INSTANTIATE_BWD(128, 8)
+#undef ATT_INSTANTIATE_BWD
 
 // ============================================================================================ host
 template <int HDP, int NKS>
@@ -634,7 +736,7 @@ static int launch_fwd(const void* qkv, void* o, float* lse, int64_t B, int64_t N
 template <int HDP, int NKS>
 static int launch_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, int64_t B,
                       int64_t N, int64_t H, float scale, hipStream_t s) {
-  const size_t lds_kv = ATT_NSLOT * (2 * AttCfg<HDP>::TILE + 256), lds_q = ATT_NSLOT * 2 * AttCfg<HDP>::TILE;
+  const size_t lds_kv = ATT_BWD_NSLOT * (2 * AttCfg<HDP>::TILE + 256), lds_q = ATT_BWD_NSLOT * 2 * AttCfg<HDP>::TILE;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<HDP, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
@@ -683,7 +785,7 @@ extern "C" int vita_attn_bwd(const void* qkv, const void* o, const void* dout, c
                              int64_t B, int64_t N, int64_t H, int64_t hd, int64_t hdp, float scale, void* stream) {
   VITA_REQUIRE(qkv && o && dout && lse && delta && dqkv && B > 0 && N > 0 && H > 0 && B < 65536 && H < 65536);
   VITA_REQUIRE((((uintptr_t)qkv | (uintptr_t)dout | (uintptr_t)dqkv | (uintptr_t)o) & 15) == 0);
-  VITA_REQUIRE(N * 3 * H * hdp * 2 < (int64_t)0xffffffffll);
+  VITA_REQUIRE((N + 64) * 3 * H * hdp * 2 < (int64_t)0xffffffffll);
   hipStream_t s = (hipStream_t)stream;
   const int64_t nks = (hd + 15) / 16;
 #define BWD_CALL(A, K) launch_bwd<A, K>(qkv, o, dout, lse, delta, dqkv, B, N, H, scale, s)
