@@ -52,8 +52,8 @@ typedef struct vita_gemm_desc {
   const void* b;
   void* c;
   const float* bias;   /* [n] fp32 or NULL (added before the activation) */
-  const void* aux_in;  /* EPI_RESIDUAL: fp32 [m][ld_aux]; EPI_GELU_BWD: bf16 pre-activation [m][ld_aux] */
-  void* aux_out;       /* EPI_GELU: bf16 pre-activation [m][ldc] */
+  const void* aux_in;  /* EPI_RESIDUAL: fp32 [m][ld_aux]; EPI_GELU_BWD: bf16 GELU derivative [m][ld_aux] (C *= aux) */
+  void* aux_out;       /* EPI_GELU: bf16 GELU'(pre-activation) [m][ldc], saved for the backward pass */
   int64_t m, n, k;
   int64_t lda, ldb, ldc, ld_aux;
   int64_t batch_outer, batch_inner;

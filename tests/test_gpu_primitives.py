@@ -26,6 +26,12 @@ def bf(t):
     return t.to(torch.bfloat16)
 
 
+def _gelu_grad(x):
+    x = x.detach().clone().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    return x.grad
+
+
 def _rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
 
@@ -75,19 +81,18 @@ def test_gemm_epilogues_and_batch(ops):
     # bias + GELU (pre-activation saved)
     c = torch.empty(m, n, dtype=torch.bfloat16, device="cuda"); u = torch.empty_like(c)
     ops.gemm(dev(A), dev(W), c, m, n, k, k, k, n, bias=dev(bias), epilogue=ops.EPI_GELU, aux_out=u)
-    torch.testing.assert_close(u.cpu().float(), pre, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(u.cpu().float(), _gelu_grad(pre), rtol=2e-2, atol=2e-2)     # saved GELU'(pre)
     torch.testing.assert_close(c.cpu().float(), torch.nn.functional.gelu(pre), rtol=2e-2, atol=2e-2)
     # bias + residual, fp32 out
     res = torch.randn(m, n)
     c2 = torch.empty(m, n, device="cuda")
     ops.gemm(dev(A), dev(W), c2, m, n, k, k, k, n, bias=dev(bias), epilogue=ops.EPI_RESIDUAL, aux_in=dev(res), ld_aux=n)
     torch.testing.assert_close(c2.cpu(), pre + res, rtol=1e-3, atol=1e-3)
-    # GELU backward multiply
-    uu = bf(torch.randn(m, n))
+    # GELU backward multiply by the saved derivative
+    uu = bf(_gelu_grad(torch.randn(m, n)))
     c3 = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
     ops.gemm(dev(A), dev(W), c3, m, n, k, k, k, n, epilogue=ops.EPI_GELU_BWD, aux_in=dev(uu), ld_aux=n)
-    x = uu.float().requires_grad_(True); torch.nn.functional.gelu(x).sum().backward()
-    torch.testing.assert_close(c3.cpu().float(), (A.float() @ W.float().t()) * x.grad, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(c3.cpu().float(), (A.float() @ W.float().t()) * uu.float(), rtol=2e-2, atol=2e-2)
     # split-k atomics + segment maps (weight-grad un-padding): rows 8->5 per segment
     dY = bf(torch.randn(k, 24)); X = bf(torch.randn(k, 40))
     full = dY.float().t() @ X.float()            # [24][40]
@@ -364,20 +369,19 @@ def test_gemm256_epilogues(ops, variant):
     pre = A.float() @ W.float().t() + bias
     c = torch.empty(m, n, dtype=torch.bfloat16, device="cuda"); u = torch.empty_like(c)
     ops.gemm(dev(A), dev(W), c, m, n, k, k, k, n, bias=dev(bias), epilogue=ops.EPI_GELU, aux_out=u, variant=variant)
-    torch.testing.assert_close(u.cpu().float(), pre, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(u.cpu().float(), _gelu_grad(pre), rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(c.cpu().float(), torch.nn.functional.gelu(pre), rtol=2e-2, atol=2e-2)
     res = torch.randn(m, n)
     c2 = torch.empty(m, n, device="cuda")
     ops.gemm(dev(A), dev(W), c2, m, n, k, k, k, n, bias=dev(bias), epilogue=ops.EPI_RESIDUAL, aux_in=dev(res), ld_aux=n,
              variant=variant)
     torch.testing.assert_close(c2.cpu(), pre + res, rtol=1e-3, atol=2e-3)
-    uu = bf(torch.randn(m, n))
+    uu = bf(_gelu_grad(torch.randn(m, n)))
     c3 = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
     Wt = W.t().contiguous()      # [K][N] for the k-strided B path (dgrad layout)
     ops.gemm(dev(A), dev(Wt), c3, m, n, k, k, n, n, b_layout=1, epilogue=ops.EPI_GELU_BWD, aux_in=dev(uu), ld_aux=n,
              variant=variant)
-    x = uu.float().requires_grad_(True); torch.nn.functional.gelu(x).sum().backward()
-    torch.testing.assert_close(c3.cpu().float(), (A.float() @ W.float().t()) * x.grad, rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(c3.cpu().float(), (A.float() @ W.float().t()) * uu.float(), rtol=2e-2, atol=2e-2)
     # alpha + bf16 out on the asymmetric-identity check
     mm = 512
     eye = torch.eye(mm).to(torch.bfloat16)

@@ -55,6 +55,14 @@ __device__ __forceinline__ float gelu_erf(float x) {
   const float tail = gelu_half_tail(x, e);
   return x * (x >= 0.f ? 1.0f - tail : tail);
 }
+// value and derivative together (the forward fc1 epilogue saves the derivative for the backward pass)
+__device__ __forceinline__ void gelu_erf_both(float x, float& g, float& dg) {
+  float e;
+  const float tail = gelu_half_tail(x, e);
+  const float cdf = x >= 0.f ? 1.0f - tail : tail;
+  g = x * cdf;
+  dg = __builtin_fmaf(x * 0.3989422804014327f, e, cdf);
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   float e;
   const float tail = gelu_half_tail(x, e);

@@ -219,20 +219,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(const GemmParams P) {
       }
       const int64_t o = c_off + m * d.ldc + n;
       if (d.epilogue == VITA_EPI_GELU) {
-        u32x2 u = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-        *reinterpret_cast<u32x2*>((uint16_t*)d.aux_out + o) = u;
+        float dg[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        for (int r = 0; r < 4; ++r) { float g; gelu_erf_both(v[r], g, dg[r]); v[r] = g; }
+        u32x2 u = {pack_bf16x2(dg[0], dg[1]), pack_bf16x2(dg[2], dg[3])};
+        *reinterpret_cast<u32x2*>((uint16_t*)d.aux_out + o) = u;
       } else if (d.epilogue == VITA_EPI_RESIDUAL) {
         const f32x4 res = *reinterpret_cast<const f32x4*>((const float*)d.aux_in + c_off + m * d.ld_aux + n);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += res[r];
       } else if (d.epilogue == VITA_EPI_GELU_BWD) {
         const u32x2 u = *reinterpret_cast<const u32x2*>((const uint16_t*)d.aux_in + c_off + m * d.ld_aux + n);
-        v[0] *= gelu_erf_grad(bf16_bits_to_f32((uint16_t)(u[0] & 0xffff)));
-        v[1] *= gelu_erf_grad(bf16_bits_to_f32((uint16_t)(u[0] >> 16)));
-        v[2] *= gelu_erf_grad(bf16_bits_to_f32((uint16_t)(u[1] & 0xffff)));
-        v[3] *= gelu_erf_grad(bf16_bits_to_f32((uint16_t)(u[1] >> 16)));
+        v[0] *= bf16_bits_to_f32((uint16_t)(u[0] & 0xffff));
+        v[1] *= bf16_bits_to_f32((uint16_t)(u[0] >> 16));
+        v[2] *= bf16_bits_to_f32((uint16_t)(u[1] & 0xffff));
+        v[3] *= bf16_bits_to_f32((uint16_t)(u[1] >> 16));
       }
       if (d.c_dtype == VITA_DT_F32) {
         *reinterpret_cast<f32x4*>((float*)d.c + o) = f32x4{v[0], v[1], v[2], v[3]};

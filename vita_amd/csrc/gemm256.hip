@@ -14,6 +14,7 @@
 //     k-strided operand   : LDS image [64 k][512 B], 32-B chunk ^ f(k), ds_read_b64_tr_b16
 //   * grouped XCD-aware raster: the 32 tiles running on one XCD form 8 M-panels x 4 N-panels
 #include "common.h"
+#include <type_traits>
 
 #define G2_BM 256
 #define G2_BK 64
@@ -356,31 +357,58 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(const Gemm2Param
       const int c4 = lane & 31;
       const int64_t n = nw0 + c4 * 4;
       const bool okc = c4 * 4 < ncol && n < d.n;      // d.n % 4 == 0 on this path
+      const int64_t nl = okc ? n : 0;                 // loads always touch valid addresses; only stores are predicated
       f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
       if (okc && d.bias) bv = *reinterpret_cast<const f32x4*>(d.bias + n);
-      const int epi = d.epilogue;
+      // 8 rows-pairs per batch: the batch's global loads (residual / saved pre-activation) are all issued
+      // before the first use, so their latency is paid once per batch instead of once per row
+      auto run = [&](auto tag) {
+        constexpr int EPI = decltype(tag)::value;
 #pragma nounroll
-      for (int it = 0; it < 16; ++it) {
-        const int row = 2 * it + (lane >> 5);
-        const int64_t m = mrow0 + row;
-        if (!okc || m >= d.m) continue;
-        f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * RS + c4 * 4) * alpha + bv;
-        const int64_t o = m * d.ldc + n;
-        if (epi == VITA_EPI_GELU) {
-          *reinterpret_cast<u32x2*>((uint16_t*)d.aux_out + o) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        for (int it0 = 0; it0 < 16; it0 += 8) {
+          f32x4 res[8];
+          u32x2 ux[8];
+          if (EPI == VITA_EPI_RESIDUAL || EPI == VITA_EPI_GELU_BWD) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-        } else if (epi == VITA_EPI_RESIDUAL) {
-          v += *reinterpret_cast<const f32x4*>((const float*)d.aux_in + m * d.ld_aux + n);
-        } else if (epi == VITA_EPI_GELU_BWD) {
-          const u32x2 u = *reinterpret_cast<const u32x2*>((const uint16_t*)d.aux_in + m * d.ld_aux + n);
-          v[0] *= gelu_erf_grad(__builtin_bit_cast(float, u[0] << 16));
-          v[1] *= gelu_erf_grad(__builtin_bit_cast(float, u[0] & 0xffff0000u));
-          v[2] *= gelu_erf_grad(__builtin_bit_cast(float, u[1] << 16));
-          v[3] *= gelu_erf_grad(__builtin_bit_cast(float, u[1] & 0xffff0000u));
+            for (int u = 0; u < 8; ++u) {
+              int64_t m = mrow0 + 2 * (it0 + u) + (lane >> 5);
+              if (m >= d.m) m = d.m - 1;
+              if (EPI == VITA_EPI_RESIDUAL) res[u] = *reinterpret_cast<const f32x4*>((const float*)d.aux_in + m * d.ld_aux + nl);
+              else ux[u] = *reinterpret_cast<const u32x2*>((const uint16_t*)d.aux_in + m * d.ld_aux + nl);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int row = 2 * (it0 + u) + (lane >> 5);
+            const int64_t m = mrow0 + row;
+            f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * RS + c4 * 4) * alpha + bv;
+            const bool ok = okc && m < d.m;
+            const int64_t o = m * d.ldc + n;
+            if (EPI == VITA_EPI_GELU) {
+              f32x4 dg;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { float g, dgr; gelu_erf_both(v[r], g, dgr); v[r] = g; dg[r] = dgr; }
+              if (ok) *reinterpret_cast<u32x2*>((uint16_t*)d.aux_out + o) = u32x2{pack_bf16x2(dg[0], dg[1]), pack_bf16x2(dg[2], dg[3])};
+            } else if (EPI == VITA_EPI_RESIDUAL) {
+              v += res[u];
+            } else if (EPI == VITA_EPI_GELU_BWD) {
+              v[0] *= __builtin_bit_cast(float, ux[u][0] << 16);
+              v[1] *= __builtin_bit_cast(float, ux[u][0] & 0xffff0000u);
+              v[2] *= __builtin_bit_cast(float, ux[u][1] << 16);
+              v[3] *= __builtin_bit_cast(float, ux[u][1] & 0xffff0000u);
+            }
+            if (ok) {
+              if (d.c_dtype == VITA_DT_F32) *reinterpret_cast<f32x4*>((float*)d.c + o) = v;
+              else *reinterpret_cast<u32x2*>((uint16_t*)d.c + o) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            }
+          }
         }
-        if (d.c_dtype == VITA_DT_F32) *reinterpret_cast<f32x4*>((float*)d.c + o) = v;
-        else *reinterpret_cast<u32x2*>((uint16_t*)d.c + o) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+      };
+      switch (d.epilogue) {
+        case VITA_EPI_GELU: run(std::integral_constant<int, VITA_EPI_GELU>{}); break;
+        case VITA_EPI_RESIDUAL: run(std::integral_constant<int, VITA_EPI_RESIDUAL>{}); break;
+        case VITA_EPI_GELU_BWD: run(std::integral_constant<int, VITA_EPI_GELU_BWD>{}); break;
+        default: run(std::integral_constant<int, VITA_EPI_NONE>{}); break;
       }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);   // staging reads done before the next pass overwrites the slice

@@ -174,7 +174,7 @@ class _BlockFn(torch.autograd.Function):
         ops.gemm(o, sh["proj_w"], x1, M, Dp, dm.AO, dm.AO, dm.AO, Dp, bias=sh["proj_b"], epilogue=ops.EPI_RESIDUAL,
                  aux_in=x, ld_aux=Dp, flops=2.0 * M * dm.D * dm.D)
         ln2, mean2, rstd2 = ops.layernorm_fwd(x1, Dp, n2w, n2b, M, dm.D, Dp, eps=blk.norm2.eps)
-        u = torch.empty(M, dm.Hp, dtype=torch.bfloat16, device=x.device)
+        u = torch.empty(M, dm.Hp, dtype=torch.bfloat16, device=x.device)   # GELU'(pre-activation), saved for backward
         g = torch.empty(M, dm.Hp, dtype=torch.bfloat16, device=x.device)
         ops.gemm(ln2, sh["fc1_w"], g, M, dm.Hp, Dp, Dp, Dp, dm.Hp, bias=sh["fc1_b"], epilogue=ops.EPI_GELU, aux_out=u,
                  flops=2.0 * M * dm.D * dm.hidden)
@@ -200,7 +200,7 @@ class _BlockFn(torch.autograd.Function):
         # ---- MLP
         d_fc2w = wgrad(dyb, Dp, g, dm.Hp, D, dm.hidden, M)
         d_fc2b = ops.colsum(dyb, Dp, M, D)
-        du = torch.empty(M, dm.Hp, dtype=torch.bfloat16, device=x.device)
+        du = torch.empty(M, dm.Hp, dtype=torch.bfloat16, device=x.device)   # GELU'(pre-activation), saved for backward
         ops.gemm(dyb, sh["fc2_w"], du, M, dm.Hp, Dp, Dp, dm.Hp, dm.Hp, b_layout=1, epilogue=ops.EPI_GELU_BWD, aux_in=u,
                  ld_aux=dm.Hp, flops=2.0 * M * D * dm.hidden)
         d_fc1w = wgrad(du, dm.Hp, ln2, Dp, dm.hidden, D, M)
