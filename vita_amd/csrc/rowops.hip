@@ -69,23 +69,23 @@ extern "C" int vita_layernorm_fwd(const float* x, int64_t ldx, const float* gamm
   return VITA_OK;
 }
 
-#define LN_BWD_MAXBLK 256
+#define LN_BWD_MAXBLK 1024
 extern "C" int64_t vita_layernorm_bwd_nblk(int64_t rows) {
-  int64_t n = (rows + 3) / 4;
+  int64_t n = (rows + 15) / 16;      // at least 4 rows per wave: the per-block partial reduction is not free
   return n < LN_BWD_MAXBLK ? n : LN_BWD_MAXBLK;
 }
 
 // NV = float4 per lane (d <= NV*256).  One wave per row; per-lane dgamma/dbeta partials live in
 // registers across the rows a wave owns and are reduced over the block's 4 waves through LDS.
 template <int NV>
-__global__ __launch_bounds__(256, 2) void ln_bwd_kernel(const void* __restrict__ dy, int64_t lddy, int dy_f32,
+__global__ __launch_bounds__(256, 3) void ln_bwd_kernel(const void* __restrict__ dy, int64_t lddy, int dy_f32,
                                                         const float* __restrict__ x, int64_t ldx,
                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, const float* __restrict__ dx_in,
                                                         float* __restrict__ dx_out, int64_t lddx, uint16_t* __restrict__ dxb,
                                                         int64_t ld_dxb, float* __restrict__ partial, int64_t rows, int d) {
   __shared__ float red[2][NV * 256];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // row addresses stay scalar
   const int nblk = gridDim.x;
   // per-lane column masks: msk[i][r] = 1 for real columns, 0 for pad columns (only the last chunk is mixed)
   f32x4 g[NV], ag[NV], ab[NV];
@@ -420,33 +420,79 @@ extern "C" int vita_cast_f32_bf16(const float* x, int64_t ldx, void* y, int64_t 
 }
 
 // each thread owns 2 adjacent columns; grid.y row chunks; fp32 atomics into a zeroed output
-__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, int f32, int64_t ld, int64_t rows,
-                                                     int64_t cols, float* __restrict__ out, int64_t rows_per_blk) {
-  const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
-  if (c >= cols) return;
+// 16-byte loads (8 bf16 / 4 fp32 columns per lane), the block's 4 waves take interleaved rows of the block's
+// row range (4 rows in flight per wave), LDS reduce over the waves, one atomic per column and block.
+template <bool F32>
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, int64_t ld, int64_t rows, int64_t cols,
+                                                     float* __restrict__ out, int64_t rows_per_blk) {
+  constexpr int CPT = F32 ? 4 : 8;
+  __shared__ float red[4][64 * CPT];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t c = ((int64_t)blockIdx.x * 64 + lane) * CPT;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_blk;
   int64_t r1 = r0 + rows_per_blk; if (r1 > rows) r1 = rows;
-  float a0 = 0.f, a1 = 0.f;
-  if (f32) {
-    const float* p = (const float*)x;
-    for (int64_t r = r0; r < r1; ++r) { a0 += p[r * ld + c]; if (c + 1 < cols) a1 += p[r * ld + c + 1]; }
-  } else {
-    const uint16_t* p = (const uint16_t*)x;
-    for (int64_t r = r0; r < r1; ++r) {
-      const uint32_t u = *reinterpret_cast<const uint32_t*>(p + r * ld + c);
-      a0 += bf16_bits_to_f32((uint16_t)(u & 0xffff)); a1 += bf16_bits_to_f32((uint16_t)(u >> 16));
+  float acc[CPT];
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) acc[j] = 0.f;
+  if (c < cols) {
+    const char* base = (const char*)x + c * (F32 ? 4 : 2);
+    const int64_t rb = ld * (F32 ? 4 : 2);
+    int64_t r = r0 + wave;
+    for (; r + 12 < r1; r += 16) {
+      u32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const u32x4*>(base + (r + 4 * u) * rb);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if constexpr (F32) {
+          { const f32x4 vf = __builtin_bit_cast(f32x4, v[u]); acc[0] += vf[0]; acc[1] += vf[1]; acc[2] += vf[2]; acc[3] += vf[3]; }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc[2 * j] += __builtin_bit_cast(float, v[u][j] << 16);
+            acc[2 * j + 1] += __builtin_bit_cast(float, v[u][j] & 0xffff0000u);
+          }
+        }
+      }
+    }
+    for (; r < r1; r += 4) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(base + r * rb);
+      if constexpr (F32) {
+        { const f32x4 vf = __builtin_bit_cast(f32x4, v); acc[0] += vf[0]; acc[1] += vf[1]; acc[2] += vf[2]; acc[3] += vf[3]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[2 * j] += __builtin_bit_cast(float, v[j] << 16);
+          acc[2 * j + 1] += __builtin_bit_cast(float, v[j] & 0xffff0000u);
+        }
+      }
     }
   }
-  atomicAdd(out + c, a0);
-  if (c + 1 < cols) atomicAdd(out + c + 1, a1);
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) red[wave][j * 64 + lane] = acc[j];
+  __syncthreads();
+  // thread t sums column slot t of the 4 waves: slot = j*64 + lane  ->  column c(lane) + j
+  for (int sidx = threadIdx.x; sidx < 64 * CPT; sidx += 256) {
+    const int j = sidx >> 6, l = sidx & 63;
+    const int64_t col = ((int64_t)blockIdx.x * 64 + l) * CPT + j;
+    if (col < cols) atomicAdd(out + col, red[0][sidx] + red[1][sidx] + red[2][sidx] + red[3][sidx]);
+  }
 }
 extern "C" int vita_colsum(const void* x, int32_t dtype, int64_t ld, int64_t rows, int64_t cols, float* out, void* stream) {
-  VITA_REQUIRE(x && out && rows > 0 && cols > 0 && ld % 2 == 0 && ld >= ((cols + 1) / 2) * 2);
+  const bool f32 = dtype == VITA_DT_F32;
+  const int cpt = f32 ? 4 : 8;
+  VITA_REQUIRE(x && out && rows > 0 && cols > 0 && ld % cpt == 0 && ld >= ((cols + cpt - 1) / cpt) * cpt);
+  VITA_REQUIRE(((uintptr_t)x & 15) == 0);
   if (hipMemsetAsync(out, 0, cols * sizeof(float), (hipStream_t)stream) != hipSuccess) return VITA_ERR_LAUNCH;
-  int64_t chunks = (rows + 127) / 128; if (chunks > 256) chunks = 256;
+  const int64_t colblk = (cols + 64 * cpt - 1) / (64 * cpt);
+  // about 2048 blocks in all, at least 64 rows per block
+  int64_t chunks = (2048 + colblk - 1) / colblk;
+  if (chunks > (rows + 63) / 64) chunks = (rows + 63) / 64;
+  if (chunks < 1) chunks = 1;
   const int64_t rpb = (rows + chunks - 1) / chunks;
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((cols + 511) / 512), (unsigned)chunks), dim3(256), 0, (hipStream_t)stream, x,
-                     dtype == VITA_DT_F32, ld, rows, cols, out, rpb);
+  dim3 grid((unsigned)colblk, (unsigned)chunks);
+  if (f32) hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, ld, rows, cols, out, rpb);
+  else hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, ld, rows, cols, out, rpb);
   VITA_CHECK_LAUNCH("vita_colsum");
   return VITA_OK;
 }

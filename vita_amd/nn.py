@@ -138,21 +138,41 @@ def attention_bwd(do, qkv, o, saved, B, N, dm: Dims):
     return dqkv
 
 
-def _split_k_for(m, n, k):
-    """split-K factor for a weight gradient (K = tokens): fill the 256 CUs with 256-row tiles, keep at least 4
-    K-tiles per split, and cap the atomic traffic (split x output bytes)."""
-    tiles = ((m + 255) // 256) * ((n + 223) // 224)
+def _wgrad_plan(m, n, k):
+    """(variant, split_k) for a weight gradient dW[m, n] = dY^T X over k tokens.
+
+    Large problems run on the 256-row LDS-DMA kernel: tile width (16 * variant) and split-K factor are chosen
+    together by a small cost model - rounds of 256 workgroups x K-tiles per split x tile width, plus the fp32
+    atomic traffic of the split (about 1.3 TB/s chip-wide, half of it assumed hidden under the MFMAs)."""
     kt = (k + 63) // 64
-    return max(1, min(8, 256 // tiles if tiles <= 256 else 1, kt // 4 if kt >= 4 else 1))
+    if m < 512 or n < 208 or kt < 8:
+        tiles = ((m + 127) // 128) * ((n + 127) // 128)
+        return 0, max(1, min(8, (2 * 256 + tiles - 1) // tiles, kt // 4 if kt >= 4 else 1))
+    tm = (m + 255) // 256
+    best = None
+    for nf in (13, 14, 16):
+        tn = (n + 16 * nf - 1) // (16 * nf)
+        for s in range(1, 17):
+            per = -(-kt // s)
+            if s > 1 and per < 4:
+                break
+            splits = -(-kt // per)
+            rounds = -(-(tm * tn * splits) // 256)
+            mfma_us = rounds * (per + 3) * (nf + 2) * 0.134
+            atomic_us = 0.5 * splits * m * n * 4 / 1.3e6 if splits > 1 else 0.0
+            cost = mfma_us + atomic_us
+            if best is None or cost < best[0]:
+                best = (cost, nf, splits)
+    return best[1], best[2]
 
 
 def wgrad(dy, lddy, x, ldx, rows_out, cols_out, k_tokens, row_seg=(0, 0), col_seg=(0, 0), m_phys=None, n_phys=None):
     """dW[logical rows_out, cols_out] fp32 = dy^T x over k_tokens rows (both operands k-strided)."""
     m = m_phys if m_phys is not None else rows_out
     n = n_phys if n_phys is not None else cols_out
-    sk = _split_k_for(m, n, k_tokens)
+    variant, sk = _wgrad_plan(m, n, k_tokens)
     out = (torch.zeros if sk > 1 else torch.empty)(rows_out, cols_out, dtype=torch.float32, device=dy.device)
-    ops.gemm(dy, x, out, m, n, k_tokens, lddy, ldx, cols_out, a_layout=1, b_layout=1, split_k=sk,
+    ops.gemm(dy, x, out, m, n, k_tokens, lddy, ldx, cols_out, a_layout=1, b_layout=1, split_k=sk, variant=variant,
              row_seg=row_seg, col_seg=col_seg, flops=2.0 * rows_out * cols_out * k_tokens)
     return out
 
