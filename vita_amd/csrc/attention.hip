@@ -163,8 +163,9 @@ __device__ __forceinline__ void dual_chain(f32x16& acc0, f32x16& acc1, const cha
 }
 
 
-template <int HDP, int NKS, int DEPTH>
-__device__ __forceinline__ void single_chain(f32x16& acc, const char* img, const LdsAddr<HDP, NKS>& la, const bf16x8 (&b)[NKS]) {
+template <int HDP, int NKS, int DEPTH, class F>
+__device__ __forceinline__ void single_chain(f32x16& acc, const char* img, const LdsAddr<HDP, NKS>& la, const bf16x8 (&b)[NKS],
+                                             F&& between) {
   bf16x8 a[DEPTH];
 #pragma unroll
   for (int j = 0; j < DEPTH && j < NKS; ++j) a[j] = la.row(img, j);
@@ -173,6 +174,7 @@ __device__ __forceinline__ void single_chain(f32x16& acc, const char* img, const
     __builtin_amdgcn_sched_barrier(0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % DEPTH], b[s], acc, 0, 0, 0);
     if (s + DEPTH < NKS) a[s % DEPTH] = la.row(img, s + DEPTH);
+    between(s);
   }
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const uint16_t* __
   constexpr int RS = C::RS, NDT = C::NDT, BUF = 2 * C::TILE, NSLOT = ATT_NSLOT;
   constexpr int DPT = 2 * (32 / C::RPI / NW);                   // DMA instructions per wave per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];   // ring of NSLOT x [K image | V image]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = blockIdx.y, b = blockIdx.z;
   const int64_t ld = 3ll * H * HDP;
   const int q0 = blockIdx.x * (NW * 32) + wave * 32;
@@ -272,25 +274,38 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const uint16_t* __
   const int ntiles = (N + 31) / 32;
   LdsAddr<HDP, NKS> la;
   la.init(lane);
+  constexpr int NI = 32 / C::RPI / NW;      // DMA pieces per wave per image
+  DmaOff<HDP, NW> off;
+  off.init(ld, wave, lane);
+  // piece p of a tile's prefetch: [0,NI) K image, [NI,2NI) V image; tiles past the end read zeros
+  auto issue_piece = [&](int tile, int buf, int p) {
+    const int tcl = tile < ntiles ? tile : ntiles;
+    const uint32_t toff = (uint32_t)tcl * (uint32_t)(32 * ld * 2);
+    if (p < NI) off.issue(rsK, toff, smem + buf * BUF, wave, p);
+    else off.issue(rsV, toff, smem + buf * BUF + C::TILE, wave, p - NI);
+  };
   auto issue = [&](int tile, int buf) {
-    dma_tile<HDP, NW>(rsK, tile * 32, ld, smem + buf * BUF, wave, lane);
-    dma_tile<HDP, NW>(rsV, tile * 32, ld, smem + buf * BUF + C::TILE, wave, lane);
+#pragma unroll
+    for (int p = 0; p < 2 * NI; ++p) issue_piece(tile, buf, p);
   };
   __syncthreads();
-  issue(0, 0);
-  if (ntiles > 1) { issue(1, 1); dma_wait_n<DPT>(); } else dma_wait();
+  issue(0, 0); issue(1, 1);
+  dma_wait_n<DPT>();               // tile 0 has landed
   ring_barrier();
   int slot = 0;
   for (int kt = 0; kt < ntiles; ++kt) {
-    const int pre = slot >= 1 ? slot - 1 : NSLOT - 1;
-    const char* kimg = smem;            // the ring position lives in the address bases (la.advance)
-    const char* vimg = smem + C::TILE;
+    const int pre = slot >= 1 ? slot - 1 : NSLOT - 1;     // slot of tile kt+2 = slot of tile kt-1
     const int kbase = kt * 32;
     if (active) {
       f32x16 sacc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-      single_chain<HDP, NKS, 4>(sacc, kimg, la, qf);
+      // the DMA of tile kt+2 is issued between the MFMAs of the S chain; the transposed V reads below are
+      // inline asm, so hipcc does not drain the DMA queue (vmcnt(0)) in front of them
+      single_chain<HDP, NKS, 4>(sacc, smem, la, qf, [&](int s) {
+#pragma unroll
+        for (int p = s; p < 2 * NI; p += NKS) issue_piece(kt + 2, pre, p);
+      });
       if (kbase + 32 > N) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -317,19 +332,34 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const uint16_t* __
       }
       l_run += rs;
       const bf16x8 pf0 = pack8(p), pf1 = pack8(p + 8);
-#pragma unroll
-      for (int i = 0; i < NDT; ++i) {
-        oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(vimg, i, 0), pf0, oacc[i], 0, 0, 0);
-        oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la.tr(vimg, i, 1), pf1, oacc[i], 0, 0, 0);
+      {
+        bf16x8 fr[3][2];      // transposed V fragments two d-tiles ahead of their MFMAs
+        fr[0][0] = la.template tr_asm<0, 0, C::TILE>(); fr[0][1] = la.template tr_asm<0, 1, C::TILE>();
+        if constexpr (NDT > 1) { fr[1][0] = la.template tr_asm<1, 0, C::TILE>(); fr[1][1] = la.template tr_asm<1, 1, C::TILE>(); }
+        static_for<NDT>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          if constexpr (i + 2 < NDT) {
+            fr[(i + 2) % 3][0] = la.template tr_asm<i + 2, 0, C::TILE>(); fr[(i + 2) % 3][1] = la.template tr_asm<i + 2, 1, C::TILE>();
+            tr_wait<8>();
+          } else if constexpr (i + 1 < NDT) {
+            tr_wait<4>();
+          } else {
+            tr_wait<0>();
+          }
+          oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % 3][0], pf0, oacc[i], 0, 0, 0);
+          oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % 3][1], pf1, oacc[i], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        });
       }
+    } else {
+      issue(kt + 2, pre);          // waves past the last query row only feed the ring
     }
-    // prefetch two tiles ahead, after this tile's last LDS read (hipcc drains vmcnt in front of tr reads)
-    if (kt + 2 < ntiles) issue(kt + 2, pre);
     slot = slot + 1 == NSLOT ? 0 : slot + 1;
     la.advance(slot == 0 ? -(NSLOT - 1) * BUF : BUF);
-    if (kt + 2 < ntiles) dma_wait_n<DPT>(); else dma_wait();
+    dma_wait_n<DPT>();             // tile kt+1 has landed
     ring_barrier();
   }
+  dma_wait();                      // zero-filled prefetches past the last tile
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l_tot;
   const int q = q0 + lq;
@@ -713,6 +743,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
                                                       uint16_t*, int, int, float);                                   \
   template __global__ void attn_bwd_dq_kernel<A, K>(const uint16_t*, const uint16_t*, const float*, const float*,    \
                                                     uint16_t*, int, int, float);
+template __global__ void attn_fwd_kernel<224, 13, 8>(const uint16_t*, uint16_t*, float*, int, int, float);
+template __global__ void attn_fwd_kernel<64, 3, 8>(const uint16_t*, uint16_t*, float*, int, int, float);
+template __global__ void attn_fwd_kernel<32, 2, 8>(const uint16_t*, uint16_t*, float*, int, int, float);
+template __global__ void attn_fwd_kernel<128, 8, 8>(const uint16_t*, uint16_t*, float*, int, int, float);
 ATT_INSTANTIATE_BWD(224, 13)
 ATT_INSTANTIATE_BWD(64, 3)
 ATT_INSTANTIATE_BWD(32, 2)
@@ -771,7 +805,7 @@ extern "C" int vita_attn_fwd(const void* qkv, void* o, float* lse, int64_t B, in
                              float scale, void* stream) {
   VITA_REQUIRE(qkv && o && lse && B > 0 && N > 0 && H > 0 && B < 65536 && H < 65536);
   VITA_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 7) == 0);
-  VITA_REQUIRE(N * 3 * H * hdp * 2 < (int64_t)0xffffffffll);
+  VITA_REQUIRE((N + 64) * 3 * H * hdp * 2 < (int64_t)0xffffffffll);
   hipStream_t s = (hipStream_t)stream;
   const int64_t nks = (hd + 15) / 16;
 #define FWD_CALL(A, K) launch_fwd<A, K>(qkv, o, lse, B, N, H, scale, s)
