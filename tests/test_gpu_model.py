@@ -213,3 +213,104 @@ def test_clip_loss_golden(golden):
                 torch.testing.assert_close(logits.cpu(), torch.from_numpy(g[f"logits_{key}"]), rtol=1e-4, atol=1e-5)
     with pytest.raises(ValueError):
         CLIPLoss(0.1, 1.5)
+
+
+# ----------------------------------------------------------------------------------------------- Stage II
+S2_IMG = (9, 5, 32, 32)                 # L = 9*1*4*4 = 144 tokens, mask 0.5 -> 72 kept
+S2_FEATS = {"numerical": [f"n{i}" for i in range(5)], "single_categorical": ["b0", "b1", "b2"],
+            "multi_categorical": {"m0": [3], "m1": [7], "m2": [6], "m3": [4]}}
+S2_IMAGING = dict(patch_size=(5, 8, 8), enc_embed_dim=129, enc_depth=2, enc_num_heads=3, mlp_ratio=4.0, mask_ratio=0.5,
+                  mask_type="random", use_enc_pe=True, circular_pe=False, patch_embed_cls="PatchEmbed",
+                  patch_in_channels=1, grad_checkpointing=True, projection_dim=32)
+
+
+def _s2_build(seed=1):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from types import SimpleNamespace
+    from vita_amd.train import MultimodalSimCLR
+    tab = SimpleNamespace(grad_checkpointing=True, embedding_dim=129, encoder_num_heads=3, encoder_mlp_ratio=4.0,
+                          encoder_num_layers=2, projection_dim=32)
+    p = O.init_stage2_params(img_shape=S2_IMG, patch_size=(5, 8, 8), enc_dim=129, enc_depth=2, enc_heads=3, tab_depth=2,
+                             n_num=5, n_single=3, multi_classes=[3, 7, 6, 4], proj_dim=32, seed=seed)
+    model = MultimodalSimCLR(list(S2_IMG), S2_IMAGING, tab, S2_FEATS)
+    sd = model.state_dict()
+    full = dict(p)
+    for k, v in sd.items():      # BatchNorm running statistics are buffers, not part of the oracle's parameter dict
+        if k not in full:
+            assert "running_" in k or "num_batches_tracked" in k, k
+            full[k] = v
+    model.load_state_dict(full, strict=True)
+    return model.cuda(), p
+
+
+def _s2_batch(B=8, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    # per-subject contrast / offset so that the token-mean features differ between subjects: BatchNorm in the projection
+    # heads divides by their batch spread, and near-identical subjects would turn the comparison into a noise test
+    imgs = torch.rand(B, *S2_IMG, generator=g) * (0.2 + 2 * torch.rand(B, 1, 1, 1, 1, generator=g)) \
+        + torch.randn(B, 1, 1, 1, 1, generator=g)
+    tabs = torch.cat([torch.randn(B, 5, generator=g), torch.randint(0, 2, (B, 3), generator=g).float(),
+                      torch.stack([torch.randint(0, n, (B,), generator=g) for n in (3, 7, 6, 4)], 1).float()], 1)
+    return imgs, tabs
+
+
+S2_OCFG = dict(patch_size=(5, 8, 8), enc_depth=2, enc_heads=3, tab_depth=2, tab_heads=3, n_num=5, n_single=3, n_multi=4,
+               mask_ratio=0.5, temperature=0.1, lambda_0=0.5)
+
+
+def test_tabular_vit_and_heads_vs_oracle():
+    model, p = _s2_build()
+    imgs, tabs = _s2_batch()
+    y = model.encoder_tabular(tabs.cuda())
+    yr = O.tabular_vit_forward(tabs, p, prefix="encoder_tabular.", num_heads=3, depth=2, n_num=5, n_single=3, n_multi=4)
+    assert y.shape == yr.shape == (8, 13, 129) and rel(y, yr) < 2e-2
+    # backward of the tabular tower alone under a fixed cotangent (no BatchNorm / softmax-temperature amplification)
+    cot = torch.randn(8, 13, 129, generator=torch.Generator().manual_seed(9))
+    (y * cot.cuda()).sum().backward()
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith("encoder_tabular.")}
+    (O.tabular_vit_forward(tabs, pr, prefix="encoder_tabular.", num_heads=3, depth=2, n_num=5, n_single=3, n_multi=4)
+     * cot).sum().backward()
+    named = dict(model.named_parameters())
+    for k, v in pr.items():
+        if v.grad is not None and named[k].requires_grad:       # enc_pos_embed is frozen (tabular_encoders.py:33)
+            assert rel(named[k].grad, v.grad) < 3e-2, (k, rel(named[k].grad, v.grad))
+    # projection head (fp32 torch ops around BatchNorm batch statistics), forward and backward
+    h = yr.mean(1).detach()
+    hg = h.clone().cuda().requires_grad_(True)
+    z = model.projector_tabular(hg)
+    hr = h.clone().requires_grad_(True)
+    zr = O.projection_head(hr, p, "projector_tabular.")
+    assert rel(z, zr) < 1e-4
+    cz = torch.randn(8, 32, generator=torch.Generator().manual_seed(10))
+    (z * cz.cuda()).sum().backward(); (zr * cz).sum().backward()
+    assert rel(hg.grad, hr.grad) < 1e-3
+
+
+def test_stage2_step_vs_oracle():
+    """Stage-II train step (both towers, activation checkpointing, CLIP loss, Adam with coupled weight decay)."""
+    model, p = _s2_build()
+    imgs, tabs = _s2_batch()
+    from vita_amd.train import FlatAdam, stage2_train_step
+    opt = FlatAdam(model.parameters(), lr=3e-3, weight_decay=1e-4)
+    noise = draw_noise(21, 8, 144)
+    loss, logits, labels = stage2_train_step(model, opt, imgs.cuda(), tabs.cuda())
+    p_ref = {k: v.clone() for k, v in p.items()}
+    loss_ref, grads_ref = O.stage2_train_step(imgs, tabs, p_ref, noise, {}, lr=3e-3, weight_decay=1e-4, **S2_OCFG)
+    assert logits.shape == (8, 8) and torch.equal(labels.cpu(), torch.arange(8))
+    assert abs(loss.item() - loss_ref.item()) / loss_ref.item() < 2e-2
+    named = dict(model.named_parameters())
+    # BatchNorm over 8 subjects followed by logits / 0.1 amplifies the towers' bf16 rounding about tenfold (the towers
+    # alone are held to 3e-2 above and in the Stage-I tests): per-tensor relative L2 within 0.15 and direction within
+    # cos > 0.99.  Tensors whose true gradient is zero (a bias in front of BatchNorm is cancelled by its mean
+    # subtraction) are held to an absolute bound instead.
+    gmax = max(g.norm().item() for g in grads_ref.values())
+    for k, gr in grads_ref.items():
+        g = named[k].grad.detach().cpu()
+        if gr.norm().item() < 1e-3 * gmax:
+            assert (g - gr).norm().item() < 1e-3 * gmax, k
+            continue
+        assert rel(g, gr) < 0.15, (k, rel(g, gr))
+        assert torch.nn.functional.cosine_similarity(g.flatten(), gr.flatten(), dim=0) > 0.99, k
+    loss2, _, _ = stage2_train_step(model, opt, imgs.cuda(), tabs.cuda())
+    assert torch.isfinite(loss2)

@@ -61,3 +61,38 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src, f
+
+
+def test_stage2_state_dict_keys_and_head_formulation():
+    """Stage-II mirror keeps the reference's module tree (models/MultimodalSimCLR.py:32-64, networks/tabular_encoders.py:
+    20-50); the oracle's projection head equals the nn.Sequential(Linear, BatchNorm1d, ReLU, Linear) it restates."""
+    from types import SimpleNamespace
+    from oracle import vita_oracle as O
+    from vita_amd.train import MultimodalSimCLR
+    feats = {"numerical": ["a", "b"], "single_categorical": ["c"], "multi_categorical": {"m0": [3], "m1": [5]}}
+    imaging = dict(patch_size=(5, 8, 8), enc_embed_dim=17, enc_depth=1, enc_num_heads=1, mlp_ratio=4.0, mask_ratio=0.5,
+                   mask_type="random", use_enc_pe=True, patch_embed_cls="PatchEmbed", patch_in_channels=1,
+                   grad_checkpointing=True, projection_dim=8)
+    tab = SimpleNamespace(grad_checkpointing=True, embedding_dim=17, encoder_num_heads=1, encoder_mlp_ratio=4.0,
+                          encoder_num_layers=1, projection_dim=8)
+    m = MultimodalSimCLR([9, 10, 16, 16], imaging, tab, feats)
+    p = O.init_stage2_params(img_shape=(9, 10, 16, 16), patch_size=(5, 8, 8), enc_dim=17, enc_depth=1, enc_heads=1,
+                             tab_depth=1, n_num=2, n_single=1, multi_classes=[3, 5], proj_dim=8)
+    sd = m.state_dict()
+    buffers = {k for k in sd if "running_" in k or "num_batches_tracked" in k}
+    assert set(sd) - buffers == set(p)
+    for k in p:
+        assert tuple(sd[k].shape) == tuple(p[k].shape), k
+    assert not m.encoder_tabular.enc_pos_embed.requires_grad
+    assert torch.equal(sd["encoder_tabular.enc_pos_embed"], p["encoder_tabular.enc_pos_embed"])
+    for k in ("encoder_tabular.numerical_fe.1.weight", "encoder_tabular.single_c_fe.0.weight",
+              "encoder_tabular.multi_c_fe.1.weight", "encoder_tabular.cls_token", "encoder_tabular.network.0.attn.qkv.weight",
+              "encoder_tabular.norm.weight", "projector_imaging.layers.0.weight", "projector_tabular.layers.3.bias"):
+        assert k in sd, k
+    assert tuple(sd["encoder_tabular.multi_c_fe.1.weight"].shape) == (5, 17)          # nn.Embedding(n_classes, D)
+    head = torch.nn.Sequential(torch.nn.Linear(17, 17, bias=False), torch.nn.BatchNorm1d(17), torch.nn.ReLU(),
+                               torch.nn.Linear(17, 8))
+    head.load_state_dict({k[len("projector_tabular.layers."):]: v for k, v in p.items()
+                          if k.startswith("projector_tabular.layers.")}, strict=False)
+    x = torch.randn(6, 17, generator=torch.Generator().manual_seed(0))
+    assert torch.allclose(head.train()(x), O.projection_head(x, p, "projector_tabular."), atol=1e-5)

@@ -6,6 +6,8 @@ attributes, return tuples and state_dict keys as the reference; the arithmetic r
   sincos_pos_embed          utils/imaging_model_related.py:8-100   (init-time table, host side)
   ImagingMaskedEncoder      networks/imaging_encoders.py:11-145
   ViTDecoder / ImagingMaskedDecoder   networks/imaging_decoders.py:40-58, 230-305
+  TabularViT                networks/tabular_encoders.py:16-112   (Stage-II other tower)
+  SimCLRProjectionHead      lightly.models.modules (call sites models/MultimodalSimCLR.py:51-53, 62-64)
 """
 from __future__ import annotations
 
@@ -19,7 +21,8 @@ from torch.utils.checkpoint import checkpoint
 from . import ops
 from .nn import Block, Dims, _Shadows, _require_cuda, layer_norm_padded, linear_padded, pad_tokens, wgrad
 
-__all__ = ["PatchEmbed", "Masker", "sincos_pos_embed", "ImagingMaskedEncoder", "ViTDecoder", "ImagingMaskedDecoder"]
+__all__ = ["PatchEmbed", "Masker", "sincos_pos_embed", "ImagingMaskedEncoder", "ViTDecoder", "ImagingMaskedDecoder",
+           "TabularViT", "SimCLRProjectionHead"]
 
 
 def _mark(t: torch.Tensor) -> torch.Tensor:
@@ -368,3 +371,90 @@ class ImagingMaskedDecoder(nn.Module):
         z = self.forward_logits_padded(x, ids_restore)
         # boundary convenience only; the fused train step uses vita_sigmoid_mse_patch on z directly
         return torch.sigmoid(z[:, 1:, :self.head_out_dim])
+
+
+# ----------------------------------------------------------------------------- Stage II: tabular tower + heads
+class TabularViT(nn.Module):
+    """Drop-in for networks/tabular_encoders.py:16-112: same constructor (args namespace + feature-name dict),
+    parameter names (numerical_fe.i, single_c_fe.i, multi_c_fe.i, cls_token, enc_pos_embed, network.i, norm) and
+    output [B, 1 + n_features, D].  The 117 per-feature tokenizers are evaluated as two batched torch ops
+    (they are a few KB of parameters); the transformer blocks and the LayerNorm run in libvita_hip.so."""
+
+    def __init__(self, args, all_feature_names: dict, **kwargs) -> None:
+        super().__init__()
+        self.grad_checkpointing = args.grad_checkpointing
+        self.embedding_dim = args.embedding_dim
+        self.all_feature_names = all_feature_names
+        self.num_numerical = len(all_feature_names["numerical"])
+        self.num_single_c = len(all_feature_names["single_categorical"])
+        self.num_multiple_c = len(all_feature_names["multi_categorical"])
+        self.num_features = self.num_numerical + self.num_single_c + self.num_multiple_c
+        D = self.embedding_dim
+        self.numerical_fe = nn.ModuleList([nn.Linear(1, D) for _ in range(self.num_numerical)])
+        self.single_c_fe = nn.ModuleList([nn.Embedding(2, D) for _ in range(self.num_single_c)])
+        self.multi_c_fe = nn.ModuleList([nn.Embedding(int(v[0]), D) for _, v in all_feature_names["multi_categorical"].items()])
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, D))
+        self.enc_pos_embed = nn.Parameter(torch.zeros(1, 1 + self.num_features, D), requires_grad=False)
+        self.network = nn.ModuleList([Block(D, args.encoder_num_heads, args.encoder_mlp_ratio, qkv_bias=True,
+                                            norm_layer=nn.LayerNorm) for _ in range(args.encoder_num_layers)])
+        self.norm = nn.LayerNorm(D)
+        self.initialize_parameters()
+
+    def initialize_parameters(self):
+        D = self.embedding_dim
+        pe = _sincos_1d(D + 1, torch.arange(self.num_features, dtype=torch.float32))
+        pe = torch.cat([torch.zeros(1, D), pe[:, :-1]], dim=0)
+        self.enc_pos_embed.data.copy_(pe.unsqueeze(0))
+        torch.nn.init.normal_(self.cls_token, std=.02)
+        self.apply(self._init_weights)
+
+    _init_weights = ImagingMaskedEncoder._init_weights
+
+    def forward_embeddings(self, x):
+        """(B, n_features) -> (B, n_features, D), feature order numerical | single | multi."""
+        nn_, ns = self.num_numerical, self.num_single_c
+        out = []
+        if nn_:
+            w = torch.stack([l.weight[:, 0] for l in self.numerical_fe])        # [n_num, D]
+            b = torch.stack([l.bias for l in self.numerical_fe])
+            out.append(x[:, :nn_, None] * w + b)
+        tables = list(self.single_c_fe) + list(self.multi_c_fe)
+        if tables:
+            sizes = torch.tensor([0] + [t.num_embeddings for t in tables[:-1]], device=x.device).cumsum(0)
+            idx = x[:, nn_:].to(torch.long) + sizes
+            out.append(torch.nn.functional.embedding(idx, torch.cat([t.weight for t in tables], dim=0)))
+        return torch.cat(out, dim=1)
+
+    def forward_padded(self, x):
+        _require_cuda(x)
+        D = self.embedding_dim
+        t = self.forward_embeddings(x.float())
+        t = torch.cat([self.cls_token.expand(t.shape[0], -1, -1), t], dim=1) + self.enc_pos_embed
+        xp = pad_tokens(t, ops.rup(D, 64))
+        for blk in self.network:
+            if self.grad_checkpointing and torch.is_grad_enabled():
+                xp = checkpoint(blk.forward_padded, xp, use_reentrant=False)
+            else:
+                xp = blk.forward_padded(xp)
+        return _mark(layer_norm_padded(xp, self.norm))
+
+    def forward(self, x: torch.Tensor, num_paddings: int = None) -> torch.Tensor:
+        if num_paddings is not None:
+            raise NotImplementedError("vita_amd.TabularViT: num_paddings is not used by the shipped configs")
+        return self.forward_padded(x)[..., :self.embedding_dim]
+
+
+class SimCLRProjectionHead(nn.Module):
+    """lightly's SimCLR projection head as the reference calls it (in, hidden, out): Linear(bias=False) ->
+    BatchNorm1d -> ReLU -> Linear.  lightly is not pinned by the reference (absent from requirements.txt) and
+    not installed here: the layout follows lightly's published SimCLR head and is an assumption.
+    A (B, D) x (D, D) GEMM at B = 32..256 is latency-sized; it stays on stock torch ops, BatchNorm with local
+    (per-rank) statistics as in the reference."""
+
+    def __init__(self, input_dim: int = 2048, hidden_dim: int = 2048, output_dim: int = 128):
+        super().__init__()
+        self.layers = nn.Sequential(nn.Linear(input_dim, hidden_dim, bias=False), nn.BatchNorm1d(hidden_dim), nn.ReLU(),
+                                    nn.Linear(hidden_dim, output_dim, bias=True))
+
+    def forward(self, x):
+        return self.layers(x)

@@ -12,8 +12,8 @@ import torch.distributed as dist
 from torch import nn
 
 from . import ops
-from .losses import recon_mse_from_logits
-from .networks import ImagingMaskedDecoder, ImagingMaskedEncoder
+from .losses import CLIPLoss, recon_mse_from_logits
+from .networks import ImagingMaskedDecoder, ImagingMaskedEncoder, SimCLRProjectionHead, TabularViT
 from .nn import bump_shadow_epoch
 
 
@@ -44,6 +44,41 @@ class ReconMAE(nn.Module):
         loss, pred = recon_mse_from_logits(z, imgs, self.patch_size, int(self.encoder_imaging.patch_p_num), mask,
                                            self.mask_loss, want_pred)
         return loss, pred, mask
+
+
+class MultimodalSimCLR(nn.Module):
+    """Stage-II model (models/MultimodalSimCLR.py:32-64, 117-154) without the Lightning harness: imaging tower
+    (masked encoder, activation checkpointing) and tabular tower, mean over all tokens (avg_token=True), SimCLR
+    projection heads, CLIPLoss (optionally with cross-GPU negatives).  Same sub-module / state_dict names."""
+
+    def __init__(self, img_shape, imaging_hparams: dict, tabular_hparams, all_feature_names: dict, temperature=0.1,
+                 lambda_0=0.5, avg_token=True, use_both_axes=True, gather_distributed=False):
+        super().__init__()
+        self.avg_token = avg_token
+        self.encoder_imaging = ImagingMaskedEncoder(img_shape=img_shape, use_both_axes=use_both_axes, **imaging_hparams)
+        D = imaging_hparams["enc_embed_dim"]
+        self.projector_imaging = SimCLRProjectionHead(D, D, imaging_hparams["projection_dim"])
+        self.encoder_tabular = TabularViT(tabular_hparams, all_feature_names=all_feature_names,
+                                          patch_num=self.encoder_imaging.patch_embed.num_patches)
+        self.projector_tabular = SimCLRProjectionHead(tabular_hparams.embedding_dim, tabular_hparams.embedding_dim,
+                                                      tabular_hparams.projection_dim)
+        self.criterion = CLIPLoss(temperature=temperature, lambda_0=lambda_0, gather_distributed=gather_distributed)
+
+    def forward_imaging(self, x):
+        y, _, _ = self.encoder_imaging(x)
+        x_img = y.mean(dim=1) if self.avg_token else y[:, 0, :]
+        return self.projector_imaging(x_img), x_img, y
+
+    def forward_tabular(self, x):
+        y = self.encoder_tabular(x)
+        x_tab = y.mean(dim=1) if self.avg_token else y[:, 0, :]
+        return self.projector_tabular(x_tab), x_tab
+
+    def training_loss(self, imgs, tabs):
+        """models/MultimodalSimCLR.py:150-154 -> (loss, logits, labels)."""
+        z_img, _, _ = self.forward_imaging(imgs)
+        z_tab, _ = self.forward_tabular(tabs)
+        return self.criterion(z_img, z_tab)
 
 
 class FlatAdam:
@@ -144,3 +179,19 @@ def stage1_train_step(model: ReconMAE, opt: FlatAdam, imgs, reducer: Optional[Bu
     else:
         opt.step()
     return loss
+
+
+def stage2_train_step(model: MultimodalSimCLR, opt: FlatAdam, imgs, tabs, reducer: Optional[BucketedAllReduce] = None,
+                      lr=None):
+    """One Stage-II step (models/MultimodalSimCLR.py:146-178 minus logging): Adam with coupled L2 weight decay,
+    lr from the caller's warmup-cosine schedule.  With a reducer (DDP), CLIPLoss(ddp_average=True) pre-scales its
+    gradient by world so that the 1/world averaging below yields the gradient of the global-batch loss."""
+    opt.zero_grad()
+    loss, logits, labels = model.training_loss(imgs, tabs)
+    loss.backward()
+    if reducer is not None:
+        reducer.finish()
+        opt.step(grad_scale=1.0 / reducer.world, lr=lr)
+    else:
+        opt.step(lr=lr)
+    return loss, logits, labels
