@@ -67,6 +67,33 @@ def cpu_baseline(frames, steps=2):
     return dt, fl / dt / 1e12, cores
 
 
+# rocprofv3 kernel names behind each timed launch group of vita_amd.ops (for roofline.traffic)
+GROUP_KERNELS = {"attn_bwd_kernels": ("attn_delta_kernel", "attn_bwd_dkdv_kernel", "attn_bwd_dq_kernel"),
+                 "attn_fwd_kernel": ("attn_fwd_kernel",)}
+
+
+def pmc_traffic(group, frames, batch, launches_per_step):
+    """HBM bytes per launch of a timed group from the newest committed PMC summary (profiles/*_traffic.json, written by
+    tools_profile_summary.py from separate FETCH_SIZE / WRITE_SIZE passes of this same command; FETCH_SIZE doubled as
+    the gfx950 guide prescribes).  None when no summary matches this workload."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        t = json.load(open(f))
+        if t.get("frames") != frames or t.get("per_gpu_batch") != batch:
+            continue
+        names = GROUP_KERNELS.get(group)
+        if names is None:       # GEMM groups mix two kernels and several tile variants per layout: not attributed
+            return None, None
+        tot, steps = 0.0, None
+        for k, v in t["kernels"].items():
+            if any(k.startswith(n) or (" " + n) in k for n in names):
+                tot += ((v["read_bytes_per_launch"] or 0) + (v["write_bytes_per_launch"] or 0)) * v["launches"]
+        steps = t.get("steps_profiled")
+        if tot and steps and launches_per_step:
+            return tot / steps / launches_per_step, os.path.basename(f)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,6 +179,11 @@ def main():
                                "traffic": None, "launches_per_step": cnt // args.steps,
                                "avg_launch_ms": round(tsec / cnt * 1e3, 4),
                                "algorithmic_gflop_per_launch": round(work / cnt / 1e9, 2)}
+            tr, src = pmc_traffic(dom, T, B, cnt // args.steps)
+            if tr is not None:
+                out["roofline"]["traffic"] = round(tr)
+                out["roofline"]["traffic_unit"] = "HBM bytes per launch"
+                out["roofline"]["traffic_source"] = "profiles/" + src
             out["kernels"] = {k: {"ms_per_step": round(v[0] / args.steps * 1e3, 3),
                                   "tflops": round(v[1] / v[0] / 1e12, 1), "launches_per_step": v[2] // args.steps}
                               for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}

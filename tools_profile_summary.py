@@ -25,10 +25,20 @@ for r in stats[:16]:
     frs = f"{2 * fr[0] * 1024 / fr[1] / 1e6:.1f}" if fr and fr[1] else "-"
     wrs = f"{wr[0] * 1024 / wr[1] / 1e6:.1f}" if wr and wr[1] else "-"
     lines.append(f"| `{n[:70]}` | {r['Calls']} | {int(r['TotalDurationNs']) / steps / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.1f} | {r['Percentage']} | {frs} | {wrs} |")
-log = open(f"{src}/trace.log").read().strip().splitlines()[-1]
+log = [l for l in open(f"{src}/trace.log").read().splitlines() if l.startswith('{"metric"')]
+js = {}
 try:
-    js = json.loads(log); lines += ["", "bench line under the profiler:", "```", json.dumps(js), "```"]
+    js = json.loads(log[-1]); lines += ["", "bench line under the profiler:", "```", json.dumps(js), "```"]
 except Exception:
     pass
+# per-kernel HBM bytes per launch (read = 2 x FETCH_SIZE KiB, write = WRITE_SIZE KiB), read by bench.py for roofline.traffic
+traffic = {"steps_profiled": steps, "frames": js.get("config", {}).get("frames"),
+           "per_gpu_batch": js.get("config", {}).get("per_gpu_batch"), "kernels": {}}
+for n in set(fetch) | set(write):
+    fr, wr = fetch.get(n), write.get(n)
+    traffic["kernels"][n] = {"launches": (fr or wr)[1],
+                             "read_bytes_per_launch": 2 * fr[0] * 1024 / fr[1] if fr and fr[1] else None,
+                             "write_bytes_per_launch": wr[0] * 1024 / wr[1] if wr and wr[1] else None}
+json.dump(traffic, open(f"profiles/{tag}_traffic.json", "w"), indent=1, sort_keys=True)
 open(f"profiles/{tag}_summary.md", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines[:24]))
