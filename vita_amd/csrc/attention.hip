@@ -22,6 +22,7 @@
 //   dQ      : workgroup = 128 query rows, sweeps 32-key K/V tiles; dQ^T = K^T dS^T.
 // Backward is deterministic (no atomics) at the price of recomputing S and dP in both kernels.
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -594,6 +595,189 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// dK/dV with two role-specialised waves per SIMD (8 waves, 128 keys per workgroup).  Waves 0-3 ("S role") own
+// K fragments and the dV^T accumulators: S chain -> P = exp2(S*c - lse) -> dV^T += dO^T P; they hand P (packed
+// bf16, the exact B operand both products use) to their partner wave through LDS.  Waves 4-7 ("dP role") own V
+// fragments and the dK^T accumulators and run one tile behind: dS = P o (dP - delta) -> dK^T += Q^T dS -> dP
+// chain of the next tile.  Each wave carries half of the accumulators (<= 256 registers), so two waves share a
+// SIMD and one's exp / dS / DMA-issue time is covered by the other's MFMAs.
+template <int HDP, int NKS>
+__global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+                                                             const float* __restrict__ delta, uint16_t* __restrict__ dqkv,
+                                                             int N, int H, float scale) {
+  using C = AttCfg<HDP>;
+  constexpr int NDT = C::NDT, TILE = C::TILE, BUF = 2 * TILE, NSLOT = ATT_BWD_NSLOT;
+  constexpr int NI = 32 / C::RPI / 8, DPT = 2 * NI;     // DMA pieces per wave per image / per tile
+  constexpr int LC = NSLOT * BUF;                       // [NSLOT][-lse*log2e (32) | delta (32)] floats
+  constexpr int XB = LC + NSLOT * 256;                  // P hand-off: [4 key blocks][2 (tile parity)][2][64 lanes][16 B]
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave >> 2, kb = wave & 3;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int64_t ld = 3ll * H * HDP, ldo = (int64_t)H * HDP;
+  const uint16_t* base = qkv + (int64_t)b * N * ld;
+  const uint32_t extent = (uint32_t)((((int64_t)N - 1) * ld + HDP) * 2);
+  const uint32_t extent_o = (uint32_t)((((int64_t)N - 1) * ldo + HDP) * 2);
+  const __amdgpu_buffer_rsrc_t rsQ = mk_rsrc(base + h * HDP, extent);
+  const __amdgpu_buffer_rsrc_t rsKV = mk_rsrc(base + ((1 + role) * H + h) * HDP, extent);      // K (S role) or V (dP role)
+  const __amdgpu_buffer_rsrc_t rsDO = mk_rsrc(dout + (int64_t)b * N * ldo + h * HDP, extent_o);
+  const __amdgpu_buffer_rsrc_t rsL = mk_rsrc(delta + ((int64_t)b * H + h) * 2 * N, (uint32_t)N * 8);
+  const bool wave0 = wave == 0;
+
+  lds_zero<HDP>(smem, XB + 4 * 2 * 2048, tid);
+  const int lk = lane & 31, hh = lane >> 5;
+  const int key = blockIdx.x * 128 + kb * 32 + lk;
+  bf16x8 frag[NKS];
+#pragma unroll
+  for (int s = 0; s < NKS; ++s)
+    frag[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+        rsKV, (uint32_t)(((int64_t)key * ld + 16 * s + 8 * hh) * 2), 0, 0));
+  f32x16 acc[NDT];
+#pragma unroll
+  for (int i = 0; i < NDT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  const float c_exp2 = scale * 1.4426950408889634f;
+  const int ntiles = (N + 31) / 32;
+
+  DmaOff<HDP, 8> offq, offo;
+  offq.init(ld, wave, lane);
+  offo.init(ldo, wave, lane);
+  auto issue_piece = [&](int tile, int buf, int p) {
+    char* bp = smem + buf * BUF;
+    const int tcl = tile < ntiles ? tile : ntiles;      // tiles past the end: every row out of range, reads zeros
+    if (p < NI) offq.issue(rsQ, (uint32_t)tcl * (uint32_t)(32 * ld * 2), bp, wave, p);
+    else if (p < 2 * NI) offo.issue(rsDO, (uint32_t)tcl * (uint32_t)(32 * ldo * 2), bp + TILE, wave, p - NI);
+    else if (wave0) {
+      typedef __attribute__((address_space(3))) void lds_void;
+      lds_void* dst = (lds_void*)(smem + LC + buf * 256);
+      const int qq = tile * 32 + (lane & 31);
+      const uint32_t voff = (uint32_t)(qq < N ? (lane < 32 ? qq : N + qq) : 2 * N) * 4;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL, dst, 4, voff, 0, 0, 0);
+    }
+  };
+  auto issue = [&](int tile, int buf) {
+#pragma unroll
+    for (int p = 0; p <= 2 * NI; ++p) issue_piece(tile, buf, p);
+  };
+  auto wait_one_tile_in_flight = [&]() {
+    if (wave0) dma_wait_n<DPT + 1>(); else dma_wait_n<DPT>();
+  };
+  // S role: rows of the Q image, transposed reads of the dO image; dP role: rows of dO, transposed reads of Q
+  LdsAddr<HDP, NKS> la;
+  la.init(lane);
+  la.advance_rows(role ? TILE : 0);
+  la.advance_tr(role ? 0 : TILE);
+  const uint32_t xlane = XB + kb * 4096 + lane * 16;
+  __syncthreads();
+  issue(0, 0); issue(1, 1);
+  wait_one_tile_in_flight();      // tile 0 has landed
+  ring_barrier();
+
+  // product against the transposed image the la.tb bases address, fragments one d-tile ahead
+  auto product = [&](const bf16x8 b0, const bf16x8 b1) {
+    bf16x8 fr[2][2];
+    fr[0][0] = la.template tr_asm<0, 0, 0>(); fr[0][1] = la.template tr_asm<0, 1, 0>();
+    static_for<NDT>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (i + 1 < NDT) {
+        fr[(i + 1) & 1][0] = la.template tr_asm<i + 1, 0, 0>(); fr[(i + 1) & 1][1] = la.template tr_asm<i + 1, 1, 0>();
+        tr_wait<4>();
+      } else {
+        tr_wait<0>();
+      }
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 1][0], b0, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 1][1], b1, acc[i], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  if (role == 0) {
+    // step t: S chain of tile t (+ DMA of tile t+2), P(t) -> partner, dV^T += dO^T(t) P(t)
+    int slot = 0;
+    for (int t = 0; t <= ntiles; ++t) {
+      const int pre = slot >= 2 ? slot - 2 : slot + NSLOT - 2;      // slot of tile t+2 = slot of tile t-2
+      f32x16 sacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+      single_chain<HDP, NKS, 3>(sacc, smem, la, frag, [&](int s) {
+        if (s == 0 || s == NKS - 1) pin_agpr(acc);
+#pragma unroll
+        for (int p = s; p <= 2 * NI; p += NKS) issue_piece(t + 2, pre, p);
+      });
+      const float* ls = reinterpret_cast<const float*>(smem + LC + slot * 256);
+      uint32_t pw[8];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(ls + 8 * rr + 4 * hh);
+        float pe[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pe[k] = fast_exp2(__builtin_fmaf(sacc[4 * rr + k], c_exp2, l4[k]));
+        pw[2 * rr] = cvt_pk(pe[0], pe[1]); pw[2 * rr + 1] = cvt_pk(pe[2], pe[3]);
+      }
+      char* xp = smem + xlane + (t & 1) * 2048;
+      *reinterpret_cast<u32x4*>(xp) = u32x4{pw[0], pw[1], pw[2], pw[3]};
+      *reinterpret_cast<u32x4*>(xp + 1024) = u32x4{pw[4], pw[5], pw[6], pw[7]};
+      product(__builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]}), __builtin_bit_cast(bf16x8, u32x4{pw[4], pw[5], pw[6], pw[7]}));
+      slot = slot + 1 == NSLOT ? 0 : slot + 1;
+      la.advance(slot == 0 ? -(NSLOT - 1) * BUF : BUF);
+      wait_one_tile_in_flight();    // tile t+1 has landed
+      ring_barrier();
+    }
+  } else {
+    // step t: dS(t-1) from the partner's P(t-1), dK^T += Q^T(t-1) dS(t-1), dP chain of tile t (+ DMA of tile t+2)
+    la.advance_tr((NSLOT - 1) * BUF);       // tile -1 lives in the (zeroed) last slot
+    int slot = 0;
+    f32x16 dpacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dpacc[r] = 0.f;
+    for (int t = 0; t <= ntiles; ++t) {
+      const int pre = slot >= 2 ? slot - 2 : slot + NSLOT - 2;
+      const int prv = slot >= 1 ? slot - 1 : NSLOT - 1;              // slot of tile t-1
+      const float* ds_ = reinterpret_cast<const float*>(smem + LC + prv * 256 + 128);
+      const char* xp = smem + xlane + ((t + 1) & 1) * 2048;
+      const u32x4 pin0 = *reinterpret_cast<const u32x4*>(xp), pin1 = *reinterpret_cast<const u32x4*>(xp + 1024);
+      uint32_t dw[8];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(ds_ + 8 * rr + 4 * hh);
+        const uint32_t w0 = rr < 2 ? pin0[2 * rr] : pin1[2 * rr - 4], w1 = rr < 2 ? pin0[2 * rr + 1] : pin1[2 * rr - 3];
+        const float p0 = __builtin_bit_cast(float, w0 << 16), p1 = __builtin_bit_cast(float, w0 & 0xffff0000u);
+        const float p2 = __builtin_bit_cast(float, w1 << 16), p3 = __builtin_bit_cast(float, w1 & 0xffff0000u);
+        dw[2 * rr] = cvt_pk(p0 * (dpacc[4 * rr] - d4[0]), p1 * (dpacc[4 * rr + 1] - d4[1]));
+        dw[2 * rr + 1] = cvt_pk(p2 * (dpacc[4 * rr + 2] - d4[2]), p3 * (dpacc[4 * rr + 3] - d4[3]));
+      }
+      product(__builtin_bit_cast(bf16x8, u32x4{dw[0], dw[1], dw[2], dw[3]}), __builtin_bit_cast(bf16x8, u32x4{dw[4], dw[5], dw[6], dw[7]}));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dpacc[r] = 0.f;
+      single_chain<HDP, NKS, 3>(dpacc, smem, la, frag, [&](int s) {
+        if (s == 0 || s == NKS - 1) pin_agpr(acc);
+#pragma unroll
+        for (int p = s; p <= 2 * NI; p += NKS) issue_piece(t + 2, pre, p);
+      });
+      slot = slot + 1 == NSLOT ? 0 : slot + 1;
+      la.advance_rows(slot == 0 ? -(NSLOT - 1) * BUF : BUF);
+      la.advance_tr(slot == 1 ? -(NSLOT - 1) * BUF : BUF);          // transposed reads address tile t's slot next step
+      wait_one_tile_in_flight();
+      ring_barrier();
+    }
+  }
+  dma_wait();      // the zero-filled prefetches past the last tile must land before the LDS is released
+  if (key < N) {
+    uint16_t* row = dqkv + ((int64_t)b * N + key) * ld + ((2 - role) * H + h) * HDP;     // S role -> dV, dP role -> dK
+    const float f = role ? scale : 1.f;
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int d = i * 32 + 8 * rr + 4 * hh;
+        *reinterpret_cast<u32x2*>(row + d) = u32x2{cvt_pk(acc[i][4 * rr] * f, acc[i][4 * rr + 1] * f),
+                                                    cvt_pk(acc[i][4 * rr + 2] * f, acc[i][4 * rr + 3] * f)};
+      }
+  }
+}
+
 template <int HDP, int NKS>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
@@ -741,6 +925,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
 #define ATT_INSTANTIATE_BWD(A, K)                                                                                      \
   template __global__ void attn_bwd_dkdv_kernel<A, K>(const uint16_t*, const uint16_t*, const float*, const float*,  \
                                                       uint16_t*, int, int, float);                                   \
+  template __global__ void attn_bwd_dkdv8_kernel<A, K>(const uint16_t*, const uint16_t*, const float*, uint16_t*, int, int,  \
+                                                       float);                                                       \
   template __global__ void attn_bwd_dq_kernel<A, K>(const uint16_t*, const uint16_t*, const float*, const float*,    \
                                                     uint16_t*, int, int, float);
 template __global__ void attn_fwd_kernel<224, 13, 8>(const uint16_t*, uint16_t*, float*, int, int, float);
@@ -771,8 +957,13 @@ template <int HDP, int NKS>
 static int launch_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, int64_t B,
                       int64_t N, int64_t H, float scale, hipStream_t s) {
   const size_t lds_kv = ATT_BWD_NSLOT * (2 * AttCfg<HDP>::TILE + 256), lds_q = ATT_BWD_NSLOT * 2 * AttCfg<HDP>::TILE;
+  const size_t lds_kv8 = ATT_BWD_NSLOT * (2 * AttCfg<HDP>::TILE + 256) + 4 * 2 * 2048;
   static bool attr = false;
+  static bool dkdv4 = false;      // VITA_ATTN_DKDV4=1: the one-wave-per-SIMD dK/dV kernel (kept for A/B measurements)
   if (!attr) {
+    const char* e = getenv("VITA_ATTN_DKDV4");
+    dkdv4 = e && e[0] == '1';
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv8_kernel<HDP, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv8);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<HDP, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<HDP, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
     attr = true;
@@ -781,8 +972,12 @@ static int launch_bwd(const void* qkv, const void* o, const void* dout, const fl
                      lse, delta, B * N, (int)N, (int)H, HDP);
   VITA_CHECK_LAUNCH("vita_attn_bwd(delta)");
   dim3 grid((unsigned)((N + 127) / 128), (unsigned)H, (unsigned)B);
-  hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDP, NKS>), grid, dim3(256), lds_kv, s, (const uint16_t*)qkv, (const uint16_t*)dout, lse,
-                     delta, (uint16_t*)dqkv, (int)N, (int)H, scale);
+  if (dkdv4)
+    hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDP, NKS>), grid, dim3(256), lds_kv, s, (const uint16_t*)qkv, (const uint16_t*)dout, lse,
+                       delta, (uint16_t*)dqkv, (int)N, (int)H, scale);
+  else
+    hipLaunchKernelGGL((attn_bwd_dkdv8_kernel<HDP, NKS>), grid, dim3(512), lds_kv8, s, (const uint16_t*)qkv, (const uint16_t*)dout,
+                       delta, (uint16_t*)dqkv, (int)N, (int)H, scale);
   VITA_CHECK_LAUNCH("vita_attn_bwd(dkdv)");
   hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, NKS>), grid, dim3(256), lds_q, s, (const uint16_t*)qkv, (const uint16_t*)dout, lse, delta,
                      (uint16_t*)dqkv, (int)N, (int)H, scale);
