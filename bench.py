@@ -1,6 +1,10 @@
 """Benchmark of the ViTa Stage-I MAE train step (BASELINE.json configs[1]) on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W [--frames T] [--batch B]
+  python bench.py --gpus N --steps K --warmup W [--frames T] [--batch B] [--workload stage1|stage2|seg_encoder]
+
+The default (stage1, T=50, B=2) is the configuration BASELINE.json's metric is quoted on.  The other workloads are
+SURVEY 8(d)'s cfg4 (Stage II contrastive step: T=5, mask 0.5, 32 subjects/GPU, activation checkpointing as in the
+yaml) and cfg5 (unmasked encoder with skip connections, N=23 041, fwd+bwd) through the same kernels.
 
 A step = forward + backward + gradient all-reduce (N>1) + Adam over one batch of synthetic
 SAX+LAX cine stacks already resident in HBM.  One JSON line is printed by rank 0.
@@ -38,6 +42,27 @@ def step_flops_per_subject(T, cfg=REF_CFG, S=9, HW=128):
     fwd = 2.0 * keep * P * D + cfg["enc_depth"] * blk_flops(keep + 1, D) + 2.0 * (keep + 1) * D * Dd \
         + cfg["dec_depth"] * blk_flops(L + 1, Dd) + 2.0 * (L + 1) * Dd * P
     return 3.0 * fwd, L, keep
+
+
+# n_classes of the 32 multi-class tabular features (selected_feaure_names.py:109-140)
+TAB_MULTI = [3, 7, 6, 6, 6, 6, 6, 4, 3, 3, 5, 5, 6, 3, 3, 8, 8, 8, 3, 6, 7, 8, 7, 8, 8, 8, 7, 8, 3, 4, 3, 3]
+TAB_NUM, TAB_SINGLE = 67, 18
+
+
+def stage2_flops_per_subject(T, ckpt, D=1025, mask_ratio=0.5):
+    """fwd = kept-patch embedding + 6 encoder blocks + 2 tabular blocks + the two heads; step = 3x fwd, 4x for the
+    checkpointed blocks."""
+    L = 9 * (T // 5) * 16 * 16
+    keep = int(L * (1 - mask_ratio))
+    nt = 1 + TAB_NUM + TAB_SINGLE + len(TAB_MULTI)
+    blocks = 6 * blk_flops(keep + 1, D) + 2 * blk_flops(nt, D)
+    rest = 2.0 * keep * 320 * D + 2 * (2.0 * D * D + 2.0 * D * 128)
+    return (4.0 if ckpt else 3.0) * blocks + 3.0 * rest, L, keep
+
+
+def seg_flops(T, ckpt, D=1025):
+    L = 9 * (T // 5) * 16 * 16
+    return (4.0 if ckpt else 3.0) * 6 * blk_flops(L + 1, D) + 3.0 * 2.0 * L * 320 * D, L
 
 
 def cpu_baseline(frames, steps=2):
@@ -99,8 +124,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=50, help="T: 50 = BASELINE.json shape, 25 = shipped yaml")
-    ap.add_argument("--batch", type=int, default=2, help="subjects per GPU (reference yaml: 2)")
+    ap.add_argument("--workload", default="stage1", choices=["stage1", "stage2", "seg_encoder"])
+    ap.add_argument("--frames", type=int, default=None, help="T: stage1 50 = BASELINE.json shape, 25 = shipped yaml; stage2 5")
+    ap.add_argument("--batch", type=int, default=None, help="subjects per GPU (yaml: stage1 2, stage2 256 global = 32 x 8)")
+    ap.add_argument("--no-ckpt", action="store_true", help="stage2 / seg_encoder without activation checkpointing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=5)
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -121,17 +148,55 @@ def main():
     if args.materialized_attention:
         vnn.DEFAULT_FLASH = False
 
-    T, B = args.frames, args.batch
+    wl = args.workload
+    T = args.frames if args.frames is not None else {"stage1": 50, "stage2": 5, "seg_encoder": 50}[wl]
+    B = args.batch if args.batch is not None else {"stage1": 2, "stage2": 32, "seg_encoder": 1}[wl]
+    ckpt = not args.no_ckpt
     img_shape = [9, T, 128, 128]
     torch.manual_seed(1)                      # reference seed (yaml general.seed / main.py:22), same on every rank
-    model = ReconMAE(img_shape=img_shape, use_both_axes=True, **REF_CFG).cuda()
-    opt = FlatAdam(model.parameters(), lr=1e-4)
-    reducer = BucketedAllReduce(opt) if world > 1 else None
     gen = torch.Generator(device="cuda").manual_seed(1 + rank)
     imgs = torch.rand(B, *img_shape, device="cuda", generator=gen)
+    if wl == "stage1":
+        model = ReconMAE(img_shape=img_shape, use_both_axes=True, **REF_CFG).cuda()
+        opt = FlatAdam(model.parameters(), lr=1e-4)
+        reducer = BucketedAllReduce(opt) if world > 1 else None
+        step = lambda: stage1_train_step(model, opt, imgs, reducer)
+    elif wl == "stage2":
+        from types import SimpleNamespace
+        from vita_amd.train import MultimodalSimCLR, stage2_train_step, warmup_cosine_lr
+        imaging = dict(REF_CFG, mask_ratio=0.5, mask_loss=True, grad_checkpointing=ckpt, projection_dim=128)
+        tab = SimpleNamespace(grad_checkpointing=ckpt, embedding_dim=1025, encoder_num_heads=5, encoder_mlp_ratio=4.0,
+                              encoder_num_layers=2, projection_dim=128)
+        feats = {"numerical": [f"n{i}" for i in range(TAB_NUM)], "single_categorical": [f"s{i}" for i in range(TAB_SINGLE)],
+                 "multi_categorical": {f"m{i}": [n] for i, n in enumerate(TAB_MULTI)}}
+        model = MultimodalSimCLR(img_shape, imaging, tab, feats, temperature=0.1, lambda_0=0.5,
+                                 gather_distributed=world > 1).cuda()
+        opt = FlatAdam(model.parameters(), lr=3e-3, weight_decay=1e-4)
+        reducer = BucketedAllReduce(opt) if world > 1 else None
+        tabs = torch.cat([torch.randn(B, TAB_NUM, device="cuda", generator=gen),
+                          torch.randint(0, 2, (B, TAB_SINGLE), device="cuda", generator=gen).float(),
+                          torch.stack([torch.randint(0, n, (B,), device="cuda", generator=gen) for n in TAB_MULTI], 1).float()], 1)
+        lr = warmup_cosine_lr(3e-3, 10, 10, 200)          # the schedule's peak (epoch = warmup_epochs)
+        step = lambda: stage2_train_step(model, opt, imgs, tabs, reducer, lr=lr)[0]
+    else:
+        from vita_amd.networks import ImagingMaskedEncoder
+        model = ImagingMaskedEncoder(img_shape=img_shape, use_both_axes=True,
+                                     **dict(REF_CFG, mask_ratio=0.0, grad_checkpointing=ckpt)).cuda()
+        opt = FlatAdam(model.parameters(), lr=5e-4)
+        reducer = BucketedAllReduce(opt) if world > 1 else None
+
+        def step():                                        # SURVEY cfg5: sum of the output and hidden states 2, 4 as the loss
+            opt.zero_grad()
+            y, hidden = model.forward_with_skip_connection(imgs)
+            loss = y.float().mean() + hidden[2].float().mean() + hidden[4].float().mean()
+            loss.backward()
+            if reducer is not None:
+                reducer.finish()
+            opt.step(grad_scale=1.0 / world)
+            return loss
 
     for _ in range(args.warmup):
-        stage1_train_step(model, opt, imgs, reducer)
+        step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -140,7 +205,7 @@ def main():
         ops.PROF = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = stage1_train_step(model, opt, imgs, reducer)
+        loss = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -153,15 +218,30 @@ def main():
         dt = t.item()
 
     if rank == 0:
-        step_fl, L, keep = step_flops_per_subject(T)
+        if wl == "stage1":
+            step_fl, L, keep = step_flops_per_subject(T)
+            metric = "CMR subjects/sec per train step (Stage I MAE)"
+            desc = (f"Stage I MAE train step (fwd+bwd+Adam), D=1025 enc6/dec2 heads5 mask0.7, "
+                    f"9x{T}x128x128 SAX+LAX, patch 5x8x8 (L={L}, keep={keep})")
+        elif wl == "stage2":
+            step_fl, L, keep = stage2_flops_per_subject(T, ckpt)
+            metric = "CMR subjects/sec per train step (Stage II CLIP)"
+            desc = (f"Stage II contrastive train step (imaging D=1025 enc6 mask0.5 + TabularViT 117 features depth2 + SimCLR heads "
+                    f"+ CLIP loss + Adam wd1e-4), 9x{T}x128x128 (L={L}, keep={keep}), activation checkpointing {'on' if ckpt else 'off'}"
+                    + (", global negatives over all ranks" if world > 1 else ""))
+        else:
+            step_fl, L = seg_flops(T, ckpt)
+            keep = L
+            metric = "CMR subjects/sec, unmasked encoder fwd+bwd with skip connections (cfg5)"
+            desc = (f"ImagingMaskedEncoder.forward_with_skip_connection fwd+bwd+Adam, D=1025 depth6 heads5, N={L + 1}, "
+                    f"activation checkpointing {'on' if ckpt else 'off'}")
         ms = dt / args.steps * 1e3
         value = world * B * args.steps / dt
         out = {
-            "metric": "CMR subjects/sec per train step (Stage I MAE)", "value": round(value, 4), "unit": "subjects/s",
+            "metric": metric, "value": round(value, 4), "unit": "subjects/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"Stage I MAE train step (fwd+bwd+Adam), D=1025 enc6/dec2 heads5 mask0.7, "
-                                   f"9x{T}x128x128 SAX+LAX, patch 5x8x8 (L={L}, keep={keep})",
+            "config": {"workload": desc,
                        "per_gpu_batch": B, "global_batch": world * B, "frames": T,
                        "parallelism": f"dp{world}", "loss": round(float(loss.detach()), 6)},
             "step_tflop_per_subject": round(step_fl / 1e12, 3),
@@ -179,7 +259,7 @@ def main():
                                "traffic": None, "launches_per_step": cnt // args.steps,
                                "avg_launch_ms": round(tsec / cnt * 1e3, 4),
                                "algorithmic_gflop_per_launch": round(work / cnt / 1e9, 2)}
-            tr, src = pmc_traffic(dom, T, B, cnt // args.steps)
+            tr, src = pmc_traffic(dom, T, B, cnt // args.steps) if wl == "stage1" else (None, None)
             if tr is not None:
                 out["roofline"]["traffic"] = round(tr)
                 out["roofline"]["traffic_unit"] = "HBM bytes per launch"
@@ -187,7 +267,7 @@ def main():
             out["kernels"] = {k: {"ms_per_step": round(v[0] / args.steps * 1e3, 3),
                                   "tflops": round(v[1] / v[0] / 1e12, 1), "launches_per_step": v[2] // args.steps}
                               for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and wl == "stage1":
             cdt, ctf, cores = cpu_baseline(args.cpu_frames)
             out["cpu_baseline"] = {"value": round(ctf * 1e12 / step_fl, 6), "unit": "subjects/s", "cores": cores, "kind": "port",
                                    "sample": f"oracle Stage-I train step, full model (D=1025 enc6/dec2), 1 subject x {args.cpu_frames} frames, "

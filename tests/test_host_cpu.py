@@ -96,3 +96,24 @@ def test_stage2_state_dict_keys_and_head_formulation():
                           if k.startswith("projector_tabular.layers.")}, strict=False)
     x = torch.randn(6, 17, generator=torch.Generator().manual_seed(0))
     assert torch.allclose(head.train()(x), O.projection_head(x, p, "projector_tabular."), atol=1e-5)
+
+
+def test_lr_schedules_match_their_libraries():
+    """warmup-cosine == transformers.get_cosine_schedule_with_warmup, cosine == torch CosineAnnealingLR (both installed)."""
+    from vita_amd.train import cosine_annealing_lr, warmup_cosine_lr
+    p = torch.nn.Parameter(torch.zeros(1))
+    try:
+        from transformers import get_cosine_schedule_with_warmup
+    except Exception:
+        get_cosine_schedule_with_warmup = None
+    if get_cosine_schedule_with_warmup is not None:
+        opt = torch.optim.Adam([p], lr=3e-3)
+        sch = get_cosine_schedule_with_warmup(opt, num_warmup_steps=10, num_training_steps=200)
+        for ep in range(205):
+            assert abs(opt.param_groups[0]["lr"] - warmup_cosine_lr(3e-3, ep, 10, 200)) < 1e-12, ep
+            opt.step(); sch.step()
+    opt = torch.optim.Adam([p], lr=3e-3)
+    sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=50, eta_min=0)
+    for ep in range(50):
+        assert abs(opt.param_groups[0]["lr"] - cosine_annealing_lr(3e-3, ep, 50)) < 1e-9, ep
+        opt.step(); sch.step()

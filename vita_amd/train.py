@@ -169,6 +169,22 @@ class BucketedAllReduce:
         self.pending = [0] * len(self.buckets)
 
 
+def warmup_cosine_lr(base_lr, step, num_warmup_steps, num_training_steps, num_cycles=0.5):
+    """lr at scheduler step `step` under transformers.get_cosine_schedule_with_warmup (the reference's "anneal"
+    scheduler, models/MultimodalSimCLR.py:107-112; Lightning steps it once per epoch, so step = epoch)."""
+    import math
+    if step < num_warmup_steps:
+        return base_lr * float(step) / float(max(1, num_warmup_steps))
+    progress = float(step - num_warmup_steps) / float(max(1, num_training_steps - num_warmup_steps))
+    return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(num_cycles) * 2.0 * progress)))
+
+
+def cosine_annealing_lr(base_lr, epoch, t_max, eta_min=0.0):
+    """Closed form of torch CosineAnnealingLR (the reference's "cosine" scheduler, models/MultimodalSimCLR.py:104-106)."""
+    import math
+    return eta_min + (base_lr - eta_min) * (1.0 + math.cos(math.pi * epoch / t_max)) / 2.0
+
+
 def stage1_train_step(model: ReconMAE, opt: FlatAdam, imgs, reducer: Optional[BucketedAllReduce] = None):
     opt.zero_grad()
     loss, _, _ = model.training_loss(imgs)
