@@ -217,6 +217,24 @@ int vita_adam_step(float* p, const float* g, float* m, float* v, int64_t n, floa
                    float beta2, float eps, float weight_decay, float grad_scale, int64_t step,
                    void* stream);
 
+/* ------------------------------------------------------------------ input pipeline
+ * Cardiac3DplusTAllAX.__getitem__ (datasets/datasets.py:403-427) on the device, for nb subjects at once:
+ *   volume = concat(lax, sax[..., z0:z0+s_sax, :]) on the slice axis            (datasets.py:414)
+ *   x=y mirror of load_im_seg_arr (datasets.py:169-171, mirror != 0) + transpose(2,3,0,1)  (datasets.py:415)
+ *   image_normalization: (v - min) / (max - min) over the subject's whole volume (utils/general.py:139-147)
+ *   frame pick: `[:, ::t_downsampling_ratio]` then the frame_to_keep indices     (datasets.py:419-424),
+ *   composed by the host into frames int32 [n_frames] (device memory, every entry in [0, T)).
+ * lax fp32 [nb][a0][a1][s_lax][T], sax fp32 [nb][a0][a1][s_sax_total][T] (the npz layout, T fastest);
+ * out fp32 [nb][s_lax+s_sax][n_frames][R][C], (R, C) = (a1, a0) when mirrored, else (a0, a1);
+ * out[b][s][k][i][j] = (volume[j][i][s][frames[k]] - min_b) / (max_b - min_b)   (mirrored), bit-exact
+ * with numpy's fp32 arithmetic.  partial: fp32 scratch of vita_cine_partial_floats(nb) elements;
+ * minmax: optional fp32 [nb][2] receiving (min, max).  Augmentations (torchvision) are out of scope. */
+int64_t vita_cine_partial_floats(int64_t nb);
+int vita_cine_prepare(const float* lax, const float* sax, int64_t nb, int64_t a0, int64_t a1,
+                      int64_t s_lax, int64_t s_sax_total, int64_t z0, int64_t s_sax, int64_t T,
+                      const int32_t* frames, int64_t n_frames, int32_t mirror, float* partial,
+                      float* minmax, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,7 @@ outputs); no reference source is copied.  Reference entry points exercised:
   utils/imaging_model_related.py:103-147 patchify / unpatchify
   utils/imaging_model_related.py:230-286 Masker
   utils/clip_loss.py:6-40               CLIPLoss
+  utils/general.py:139-147              image_normalization (definition only; the module imports skimage)
 """
 import hashlib
 import os
@@ -174,5 +175,40 @@ def g6_patchify():
          pred=pred.numpy(), mask=mask.numpy(), mse_all=mse_all.numpy(), mse_masked=mse_masked.numpy())
 
 
+def _reference_function(rel_path, name):
+    """Execute ONE function definition of a reference module whose top-level imports are not installed here
+    (utils/general.py imports skimage): the definition is parsed out of the file and compiled as is."""
+    import ast
+    from typing import Union
+    path = os.path.join(REF, rel_path)
+    tree = ast.parse(open(path).read(), filename=path)
+    node = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name)
+    ns = {"np": np, "torch": torch, "Union": Union}
+    exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), ns)
+    return ns[name]
+
+
+def g7_cine():
+    """image_normalization (utils/general.py:139-147) applied where Cardiac3DplusTAllAX.__getitem__ applies it
+    (datasets/datasets.py:414-417): on the (S, T, H, W) volume after the x=y mirror, LAX+SAX concat and transpose.
+    The stored arrays are synthetic (UK Biobank data is restricted): fp32 'intensities' [H, W, S, T]."""
+    image_normalization = _reference_function("utils/general.py", "image_normalization")
+    out = {}
+    for tag, (H, W, s_tot, T, z_min, z_num, seed) in {"a": (16, 24, 8, 10, 1, 6, 0), "b": (16, 16, 7, 50, 1, 6, 1)}.items():
+        rng = np.random.RandomState(seed)
+        lax = (rng.rand(H, W, 3, T) * 900 + rng.randn(H, W, 3, T) * 30).astype(np.float32)
+        sax = (rng.rand(H, W, s_tot, T) * 1400 - 100).astype(np.float32)
+        sax_im = np.moveaxis(sax[..., z_min:z_min + z_num, :], 1, 0)          # datasets.py:166-167,170
+        lax_im = np.moveaxis(lax, 1, 0)                                        # datasets.py:171
+        im = np.transpose(np.concatenate([lax_im, sax_im], axis=2), (2, 3, 0, 1))   # datasets.py:414-415
+        norm = image_normalization(im)                                         # datasets.py:417
+        assert norm.dtype == np.float32
+        out.update({f"{tag}_lax": lax, f"{tag}_sax": sax, f"{tag}_z": np.array([z_min, z_num]), f"{tag}_norm": norm})
+    save("g7_cine.npz", **out)
+
+
 if __name__ == "__main__":
-    g1_patch_embed(); g2_pos_embed(); g3_masker(); g4_gather(); g5_clip(); g6_patchify()
+    only = sys.argv[1:]
+    for fn in (g1_patch_embed, g2_pos_embed, g3_masker, g4_gather, g5_clip, g6_patchify, g7_cine):
+        if not only or fn.__name__.split("_")[0] in only:
+            fn()

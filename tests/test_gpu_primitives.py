@@ -412,3 +412,49 @@ def test_gemm256_wgrad_maps(ops, variant, split_k):
     ops.gemm(dev(dY), dev(X), out2, n_out_phys, k_in_phys, tokens, n_out_phys, k_in_phys, len(keepc), a_layout=1, b_layout=1,
              split_k=split_k, col_seg=(88, 80), variant=variant)
     torch.testing.assert_close(out2.cpu(), full[:, keepc], rtol=1e-3, atol=2e-2)
+
+
+# ----------------------------------------------------------------------------- input pipeline
+def test_cine_prepare_golden_bit_exact(ops, golden):
+    """vita_cine_prepare == reference image_normalization on the assembled volume (g7), bit for bit."""
+    from vita_amd.data import prepare_cine_batch
+    g = golden("g7_cine.npz")
+    for tag in ("a", "b"):
+        lax, sax = g[f"{tag}_lax"], g[f"{tag}_sax"]
+        z_min, z_num = (int(v) for v in g[f"{tag}_z"])
+        T = lax.shape[-1]
+        out, mm = prepare_cine_batch(dev(torch.from_numpy(lax))[None], dev(torch.from_numpy(sax))[None], z0=z_min,
+                                     sax_slice_num=z_num, time_frame=T, return_minmax=True)
+        assert np.array_equal(out[0].cpu().numpy(), g[f"{tag}_norm"])
+        window = sax[:, :, z_min:z_min + z_num]
+        assert mm[0, 0].item() == min(lax.min(), window.min()) and mm[0, 1].item() == max(lax.max(), window.max())
+        for keep, ratio in ((5, 1), (3, 2)):
+            tf = len(range(0, T, ratio))
+            out = prepare_cine_batch(dev(torch.from_numpy(lax))[None], dev(torch.from_numpy(sax))[None], z0=z_min,
+                                     sax_slice_num=z_num, time_frame=tf, frame_to_keep=keep, t_downsampling_ratio=ratio)
+            ref = O.cine_getitem(lax, sax, z_min=z_min, z_num=z_num, time_frame=tf, frame_to_keep=keep, t_downsampling_ratio=ratio)
+            assert np.array_equal(out[0].cpu().numpy(), ref)
+
+
+def test_cine_prepare_batch_full_size(ops):
+    """Two full-size subjects (128x128, 3 LAX + 6 of 11 SAX slices, 50 frames): per-subject extrema, oracle equality,
+    range [0, 1] with both ends attained, and the un-mirrored variant is the H/W transpose."""
+    from vita_amd.data import prepare_cine_batch
+    rng = np.random.RandomState(5)
+    lax = (rng.rand(2, 128, 128, 3, 50) * 700).astype(np.float32)
+    sax = (rng.rand(2, 128, 128, 11, 50) * 1300 - 40).astype(np.float32)
+    sax[1] *= 0.5
+    out = prepare_cine_batch(dev(torch.from_numpy(lax)), dev(torch.from_numpy(sax)), z0=3, sax_slice_num=6, time_frame=50)
+    assert out.shape == (2, 9, 50, 128, 128)
+    for b in range(2):
+        ref = O.cine_getitem(lax[b], sax[b], z_min=3, z_num=6)
+        assert np.array_equal(out[b].cpu().numpy(), ref)
+        assert out[b].min().item() == 0.0 and out[b].max().item() == 1.0
+    plain = prepare_cine_batch(dev(torch.from_numpy(lax)), dev(torch.from_numpy(sax)), z0=3, sax_slice_num=6, time_frame=50,
+                               frame_to_keep=5, mirror=False)
+    idx = [round(i * 49 / 4) for i in range(5)]
+    assert torch.equal(plain, out[:, :, idx].transpose(-1, -2))
+    with pytest.raises(ValueError):
+        prepare_cine_batch(dev(torch.from_numpy(lax)), dev(torch.from_numpy(sax)), z0=8, sax_slice_num=6)
+    with pytest.raises(RuntimeError):
+        prepare_cine_batch(torch.from_numpy(lax), torch.from_numpy(sax))

@@ -117,3 +117,54 @@ def test_lr_schedules_match_their_libraries():
     for ep in range(50):
         assert abs(opt.param_groups[0]["lr"] - cosine_annealing_lr(3e-3, ep, 50)) < 1e-9, ep
         opt.step(); sch.step()
+
+
+def test_frame_indices_and_slice_window():
+    """Host side of the input-pipeline contract (datasets/datasets.py:162-165, 419-424)."""
+    import numpy as np
+    from oracle import vita_oracle as O
+    from vita_amd.data import frame_indices, sax_slice_window
+    assert frame_indices(50, 50, 50) == list(range(50)) and frame_indices(50, 50, None) == list(range(50))
+    for keep in (5, 25, 2, 7):
+        step = 49 / (keep - 1)
+        assert frame_indices(50, 50, keep) == [round(i * step) for i in range(keep)]
+    assert frame_indices(50, 50, 25)[:4] == [0, 2, 4, 6]          # 49/24 * 3 = 6.125; round half to even elsewhere
+    assert frame_indices(50, 25, 5, t_downsampling_ratio=2) == [0, 12, 24, 36, 48]
+    with pytest.raises(IndexError):
+        frame_indices(20, 50, 5)                                   # time_frame larger than the stored cine
+    rng = np.random.RandomState(0)
+    for first in (0, 3, 9):
+        seg = np.zeros((8, 8, 12, 4), dtype=np.int32)
+        seg[2:4, 2:4, first:, 0] = 1
+        seg[..., 1:] = rng.randint(0, 4, seg[..., 1:].shape)
+        assert sax_slice_window(torch.from_numpy(seg), 6) == O.sax_slice_window(seg, 6)
+
+
+def test_load_pretrained_weights_prefix_filter(tmp_path):
+    """initializers/initialize_model.py:106-139: key-prefix filter, strict=False, freezing."""
+    from vita_amd.data import filter_state_dict, load_pretrained_weights
+    from vita_amd.train import ReconMAE
+    cfg = dict(patch_size=(5, 8, 8), enc_embed_dim=17, enc_depth=1, enc_num_heads=1, dec_embed_dim=17, dec_depth=1,
+               dec_num_heads=1, mlp_ratio=4.0, mask_ratio=0.7, mask_type="random", use_enc_pe=True,
+               patch_embed_cls="PatchEmbed", patch_in_channels=1)
+    torch.manual_seed(0)
+    src = ReconMAE(img_shape=[9, 10, 16, 16], use_both_axes=True, **cfg)
+    torch.manual_seed(1)
+    dst = ReconMAE(img_shape=[9, 5, 16, 16], use_both_axes=True, **cfg)      # other T: pos-embed shapes differ
+    path = tmp_path / "last.ckpt"
+    torch.save({"state_dict": src.state_dict(), "epoch": 3}, path)
+    before = {k: v.clone() for k, v in dst.state_dict().items()}
+    res = load_pretrained_weights(dst, path, freeze_encoder=True, loading_parts=["encoder_imaging"],
+                                  exclude_parts=["encoder_imaging.enc_pos_embed"])
+    assert not res.unexpected_keys and any(k.startswith("decoder_imaging") for k in res.missing_keys)
+    after, ref = dst.state_dict(), src.state_dict()
+    for k in after:
+        if k.startswith("encoder_imaging") and k != "encoder_imaging.enc_pos_embed":
+            assert torch.equal(after[k], ref[k]), k
+        else:
+            assert torch.equal(after[k], before[k]), k
+    for n, p in dst.named_parameters():
+        assert p.requires_grad == (not n.startswith("encoder_imaging") and not n.endswith("pos_embed")), n
+    kept = filter_state_dict(ref, ["decoder_imaging"], ["decoder_imaging.dec_pos_embed"])
+    assert kept and all(k.startswith("decoder_imaging") and "dec_pos_embed" not in k for k in kept)
+    assert filter_state_dict(ref) == dict(ref)

@@ -165,3 +165,23 @@ def test_block_restatement_vs_independent_formulations():
     x1 = x + ref
     h = torch.nn.functional.gelu(torch.nn.functional.linear(O.layer_norm(x1, p["norm2.weight"], p["norm2.bias"]), p["mlp.fc1.weight"], p["mlp.fc1.bias"]))
     torch.testing.assert_close(out, x1 + torch.nn.functional.linear(h, p["mlp.fc2.weight"], p["mlp.fc2.bias"]), rtol=1e-4, atol=1e-5)
+
+
+def test_g7_cine_normalization(golden):
+    """image_normalization (reference function, utils/general.py:139-147) on the assembled (S,T,H,W) volume."""
+    g = golden("g7_cine.npz")
+    for tag in ("a", "b"):
+        lax, sax = g[f"{tag}_lax"], g[f"{tag}_sax"]
+        z_min, z_num = (int(v) for v in g[f"{tag}_z"])
+        mine = O.cine_getitem(lax, sax, z_min=z_min, z_num=z_num)
+        assert mine.dtype == np.float32 and np.array_equal(mine, g[f"{tag}_norm"])
+        assert mine.min() == 0.0 and mine.max() == 1.0
+        # frame subsampling indexes the normalised volume (normalisation sees every stored frame)
+        T = lax.shape[-1]
+        sub = O.cine_getitem(lax, sax, z_min=z_min, z_num=z_num, time_frame=T, frame_to_keep=5, t_downsampling_ratio=1)
+        step = (T - 1) / 4
+        assert np.array_equal(sub, g[f"{tag}_norm"][:, [round(i * step) for i in range(5)]])
+        # LAX slices first, x=y mirror: out[s, t, i, j] = stored[j, i, s, t]
+        lo, hi = min(lax.min(), sax[:, :, z_min:z_min + z_num].min()), max(lax.max(), sax[:, :, z_min:z_min + z_num].max())
+        assert mine[1, 2, 3, 5] == (lax[5, 3, 1, 2] - lo) / (hi - lo)
+        assert mine[4, 2, 3, 5] == (sax[5, 3, z_min + 1, 2] - lo) / (hi - lo)
