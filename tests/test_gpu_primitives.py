@@ -301,8 +301,12 @@ def test_flash_attention_fwd(ops, B, N, H, hd):
     torch.testing.assert_close(lse.cpu(), lse_ref, rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("B,N,H,hd", [(2, 197, 5, 205), (1, 64, 3, 43), (2, 333, 2, 128), (1, 700, 5, 205), (1, 31, 1, 32)])
-def test_flash_attention_bwd(ops, B, N, H, hd):
+@pytest.mark.parametrize("handoff", [True, False], ids=["ds_handoff", "dq_recompute"])
+@pytest.mark.parametrize("B,N,H,hd", [(2, 197, 5, 205), (1, 64, 3, 43), (2, 333, 2, 128), (1, 700, 5, 205), (1, 31, 1, 32),
+                                      (1, 512, 2, 205), (2, 257, 1, 205), (1, 129, 3, 43)])
+def test_flash_attention_bwd(ops, B, N, H, hd, handoff):
+    """Both dQ paths: dS tiles handed from the dK/dV kernel through the HBM scratch (default), and the dQ kernel that
+    recomputes S / dP (ws == NULL).  Sizes cover N below one tile, N = k*256, and one row past a 128 / 256 boundary."""
     torch.manual_seed(N + 1)
     hdp = ops.rup(hd, 32)
     qkv = torch.zeros(B, N, 3, H, hdp)
@@ -320,7 +324,7 @@ def test_flash_attention_bwd(ops, B, N, H, hd):
     qd = qb.cuda()
     ops.attn_fwd(qd, o, lse, B, N, H, hd, hdp, scale)
     dqkv = torch.full((B, N, 3, H, hdp), float("nan"), dtype=torch.bfloat16, device="cuda")
-    ops.attn_bwd(qd, o, dob.cuda(), lse, dqkv, B, N, H, hd, hdp, scale)
+    ops.attn_bwd(qd, o, dob.cuda(), lse, dqkv, B, N, H, hd, hdp, scale, handoff=handoff)
     got = dqkv.cpu().float()
     assert torch.isfinite(got).all() and not got[..., hd:].any()
     for i, name in enumerate("qkv"):

@@ -233,6 +233,7 @@ __device__ __forceinline__ void ring_barrier() {
 }
 #define ATT_NSLOT 3
 #define ATT_BWD_NSLOT 4   // the software-pipelined dK/dV kernel keeps tiles t .. t+3 in the ring
+#define ATT_DQDS_NSLOT 4  // ring depth of the streaming dQ kernel (K image + 8 dS tiles = 32 KiB per slot at hdp 224)
 
 template <int HDP>
 __device__ __forceinline__ void lds_zero(char* smem, int bytes, int tid) {
@@ -605,6 +606,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const uint16_t* _
 template <int HDP, int NKS>
 __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                              const float* __restrict__ delta, uint16_t* __restrict__ dqkv,
+                                                             uint16_t* __restrict__ ds_out, int QT, int KTP,
                                                              int N, int H, float scale) {
   using C = AttCfg<HDP>;
   constexpr int NDT = C::NDT, TILE = C::TILE, BUF = 2 * TILE, NSLOT = ATT_BWD_NSLOT;
@@ -729,6 +731,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
     // step t: dS(t-1) from the partner's P(t-1), dK^T += Q^T(t-1) dS(t-1), dP chain of tile t (+ DMA of tile t+2)
     la.advance_tr((NSLOT - 1) * BUF);       // tile -1 lives in the (zeroed) last slot
     int slot = 0;
+    // dS hand-off to attn_bwd_dq_ds_kernel: tile (key block kt, query tile qt) = dS^T[32 keys][32 queries] bf16, 2 KiB,
+    // at ((bh * KTP + kt) * QT + qt) * 2 KiB; inside a tile byte = key*64 + hh*32 + rr*8 + j*2 for query 8rr + 4hh + j,
+    // i.e. every lane's eight packed words are 32 contiguous bytes and a wave writes its tile as one contiguous 2 KiB.
+    const int kt = blockIdx.x * 4 + kb;
+    const bool ds_store = ds_out != nullptr && __builtin_amdgcn_readfirstlane(kt * 32) < N;
+    // one descriptor (SGPRs) per (head, key block) row of tiles + one 32-bit lane offset: no 64-bit pointer in VGPRs
+    const __amdgpu_buffer_rsrc_t rsS = mk_rsrc(ds_out + (((int64_t)b * H + h) * KTP + kt) * QT * 1024, (uint32_t)QT * 2048u);
+    const uint32_t ds_lane = lk * 64 + hh * 32;
     f32x16 dpacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dpacc[r] = 0.f;
@@ -747,6 +757,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
         const float p2 = __builtin_bit_cast(float, w1 << 16), p3 = __builtin_bit_cast(float, w1 & 0xffff0000u);
         dw[2 * rr] = cvt_pk(p0 * (dpacc[4 * rr] - d4[0]), p1 * (dpacc[4 * rr + 1] - d4[1]));
         dw[2 * rr + 1] = cvt_pk(p2 * (dpacc[4 * rr + 2] - d4[2]), p3 * (dpacc[4 * rr + 3] - d4[3]));
+      }
+      if (ds_store && t >= 1) {       // dS^T of tile t-1, exactly the bf16 values the dK product consumes
+        const uint32_t toff = (uint32_t)(t - 1) * 2048u;      // wave-uniform
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{dw[0], dw[1], dw[2], dw[3]}, rsS, ds_lane, toff, 2);       // aux 2 = nt
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{dw[4], dw[5], dw[6], dw[7]}, rsS, ds_lane + 16, toff, 2);
       }
       product(__builtin_bit_cast(bf16x8, u32x4{dw[0], dw[1], dw[2], dw[3]}), __builtin_bit_cast(bf16x8, u32x4{dw[4], dw[5], dw[6], dw[7]}));
 #pragma unroll
@@ -920,13 +935,142 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// dQ from the dS tiles that attn_bwd_dkdv8_kernel left in HBM: dQ^T (d x q) += K^T (d x keys) dS^T (keys x q), a pure
+// streaming product - no S / dP recompute, no exp.  Workgroup = 256 queries (8 waves x one 32-query tile), sweeps the
+// 32-key tiles: the K image (shared) and each wave's own 2 KiB dS tile arrive by LDS-DMA through an NSLOT ring, both
+// operands are transposed LDS reads (the dS image is plain [32 keys][64 B]: a 32-lane half reads 256 contiguous bytes,
+// conflict-free).  Every dS element is read from HBM exactly once, so the kernel runs at the HBM rate of
+// N^2 * 2 B per head.  The query order inside a tile is the producer's register order: column p of the image is query
+// 8*((p>>2)&3) + 4*(p>>4) + (p&3); the permutation only relabels the output rows.
+template <int HDP, int NKS, int NSLOT>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dq_ds_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ ds,
+                                                                uint16_t* __restrict__ dqkv, int QT, int KTP, int N, int H,
+                                                                float scale) {
+  using C = AttCfg<HDP>;
+  constexpr int RS = C::RS, NDT = C::NDT, TILE = C::TILE, BUF = TILE + 8 * 2048;   // ring slot = [ K image | 8 dS tiles ]
+  constexpr int NI = 32 / C::RPI / 8, DPT = NI + 2;                                 // DMA instructions per wave per tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int64_t ld = 3ll * H * HDP;
+  const uint16_t* base = qkv + (int64_t)b * N * ld;
+  const uint32_t extent = (uint32_t)((((int64_t)N - 1) * ld + HDP) * 2);
+  const __amdgpu_buffer_rsrc_t rsK = mk_rsrc(base + (H + h) * HDP, extent);
+  const uint32_t ds_bytes = (uint32_t)KTP * (uint32_t)QT * 2048u;
+  const __amdgpu_buffer_rsrc_t rsDS = mk_rsrc(ds + ((int64_t)b * H + h) * KTP * QT * 1024, ds_bytes);
+  const int qt = blockIdx.x * 8 + wave;                 // this wave's query tile
+  const bool qt_ok = qt < QT;                           // waves past the last tile read zeros
+  const int ntiles = (N + 31) / 32;
+
+  lds_zero<HDP>(smem, NSLOT * BUF, tid);
+  f32x16 dq[NDT];
+#pragma unroll
+  for (int i = 0; i < NDT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+
+  LdsAddr<HDP, NKS> la;
+  la.init(lane);
+  // transposed read of the dS image: group g = lane>>4 takes rows 4*(g>>1) + tq (+8 for the second half of a k-step,
+  // +16 for k-step 1), columns 16*(g&1) + 4*tp .. +3 - the key order of LdsAddr::tr_asm's K^T fragments
+  uint32_t dsb;
+  {
+    const int g = lane >> 4, t = lane & 15, tq = t >> 2, tp = t & 3;
+    dsb = TILE + wave * 2048 + (4 * (g >> 1) + tq) * 64 + (16 * (g & 1) + 4 * tp) * 2;
+  }
+  DmaOff<HDP, 8> offk;
+  offk.init(ld, wave, lane);
+  const uint32_t ds_voff = qt_ok ? (uint32_t)qt * 2048u + lane * 16 : 0xfffffff0u;
+  auto issue_piece = [&](int tile, int buf, int p) {
+    char* bp = smem + buf * BUF;
+    if (p < NI) {
+      const int tcl = tile < ntiles ? tile : ntiles;      // tiles past the end: every row out of range, reads zeros
+      offk.issue(rsK, (uint32_t)tcl * (uint32_t)(32 * ld * 2), bp, wave, p);
+    } else {
+      typedef __attribute__((address_space(3))) void lds_void;
+      const int j = p - NI;
+      const uint32_t toff = (uint32_t)tile * (uint32_t)QT * 2048u + j * 1024;     // past KTP: beyond the descriptor, zeros
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsDS, (lds_void*)(bp + TILE + wave * 2048 + j * 1024), 16,
+                                               qt_ok ? ds_voff + toff : 0xfffffff0u, 0, 0, 0);
+    }
+  };
+  auto issue = [&](int tile, int buf) {
+#pragma unroll
+    for (int p = 0; p < DPT; ++p) issue_piece(tile, buf, p);
+  };
+  auto ds_frag = [&](auto s2c) {
+    constexpr int S2 = decltype(s2c)::value;
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v2i lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(dsb), "n"(S2 * 1024) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(dsb), "n"(S2 * 1024 + 512) : "memory");
+    v4i v = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < NSLOT - 1; ++t) issue(t, t);
+  dma_wait_n<DPT>();               // tiles 0 .. NSLOT-3 have landed
+  ring_barrier();
+  int slot = 0;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int pre = slot >= 1 ? slot - 1 : NSLOT - 1;     // slot of tile t + NSLOT - 1 = slot of tile t - 1
+    const bf16x8 b0 = ds_frag(std::integral_constant<int, 0>{}), b1 = ds_frag(std::integral_constant<int, 1>{});
+    bf16x8 fr[3][2];
+    fr[0][0] = la.template tr_asm<0, 0, 0>(); fr[0][1] = la.template tr_asm<0, 1, 0>();
+    if constexpr (NDT > 1) { fr[1][0] = la.template tr_asm<1, 0, 0>(); fr[1][1] = la.template tr_asm<1, 1, 0>(); }
+    static_for<NDT>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (i + 2 < NDT) {
+        fr[(i + 2) % 3][0] = la.template tr_asm<i + 2, 0, 0>(); fr[(i + 2) % 3][1] = la.template tr_asm<i + 2, 1, 0>();
+        tr_wait<8>();
+      } else if constexpr (i + 1 < NDT) {
+        tr_wait<4>();
+      } else {
+        tr_wait<0>();
+      }
+      dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % 3][0], b0, dq[i], 0, 0, 0);
+      dq[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % 3][1], b1, dq[i], 0, 0, 0);
+      if constexpr (i < DPT) issue_piece(tile + NSLOT - 1, pre, i);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if constexpr (NDT < DPT) {
+#pragma unroll
+      for (int p = NDT; p < DPT; ++p) issue_piece(tile + NSLOT - 1, pre, p);
+    }
+    slot = slot + 1 == NSLOT ? 0 : slot + 1;
+    la.advance_tr(slot == 0 ? -(NSLOT - 1) * BUF : BUF);
+    dsb += slot == 0 ? -(NSLOT - 1) * BUF : BUF;
+    dma_wait_n<(NSLOT - 2) * DPT>();     // tile t+1 has landed
+    ring_barrier();
+  }
+  dma_wait();      // prefetches past the last tile
+  const int lq = lane & 31, hh = lane >> 5;
+  const int q = qt * 32 + 8 * ((lq >> 2) & 3) + 4 * (lq >> 4) + (lq & 3);
+  if (qt_ok && q < N) {
+    uint16_t* qrow = dqkv + ((int64_t)b * N + q) * ld + h * HDP;
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int d = i * 32 + 8 * rr + 4 * hh;
+        *reinterpret_cast<u32x2*>(qrow + d) = u32x2{cvt_pk(dq[i][4 * rr] * scale, dq[i][4 * rr + 1] * scale),
+                                                     cvt_pk(dq[i][4 * rr + 2] * scale, dq[i][4 * rr + 3] * scale)};
+      }
+  }
+}
+
 // Explicit instantiations: with the generic-lambda / if-constexpr bodies above hipcc (ROCm 7.2) silently skips the
 // host-side implicit instantiation of attn_bwd_dq_kernel from launch_bwd (undefined kernel handle at load time).
 #define ATT_INSTANTIATE_BWD(A, K)                                                                                      \
   template __global__ void attn_bwd_dkdv_kernel<A, K>(const uint16_t*, const uint16_t*, const float*, const float*,  \
                                                       uint16_t*, int, int, float);                                   \
-  template __global__ void attn_bwd_dkdv8_kernel<A, K>(const uint16_t*, const uint16_t*, const float*, uint16_t*, int, int,  \
-                                                       float);                                                       \
+  template __global__ void attn_bwd_dkdv8_kernel<A, K>(const uint16_t*, const uint16_t*, const float*, uint16_t*, uint16_t*, \
+                                                       int, int, int, int, float);                                   \
+  template __global__ void attn_bwd_dq_ds_kernel<A, K, ATT_DQDS_NSLOT>(const uint16_t*, const uint16_t*, uint16_t*, int,   \
+                                                                       int, int, int, float);                        \
   template __global__ void attn_bwd_dq_kernel<A, K>(const uint16_t*, const uint16_t*, const float*, const float*,    \
                                                     uint16_t*, int, int, float);
 template __global__ void attn_fwd_kernel<224, 13, 8>(const uint16_t*, uint16_t*, float*, int, int, float);
@@ -953,11 +1097,16 @@ static int launch_fwd(const void* qkv, void* o, float* lse, int64_t B, int64_t N
   return VITA_OK;
 }
 
+// dS hand-off geometry: query tiles QT = ceil(N/32), key blocks padded to the dK/dV grid KTP = 4 * ceil(N/128)
+static inline int64_t att_qt(int64_t N) { return (N + 31) / 32; }
+static inline int64_t att_ktp(int64_t N) { return 4 * ((N + 127) / 128); }
+
 template <int HDP, int NKS>
-static int launch_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, int64_t B,
-                      int64_t N, int64_t H, float scale, hipStream_t s) {
+static int launch_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, void* ws,
+                      int64_t B, int64_t N, int64_t H, float scale, hipStream_t s) {
   const size_t lds_kv = ATT_BWD_NSLOT * (2 * AttCfg<HDP>::TILE + 256), lds_q = ATT_BWD_NSLOT * 2 * AttCfg<HDP>::TILE;
   const size_t lds_kv8 = ATT_BWD_NSLOT * (2 * AttCfg<HDP>::TILE + 256) + 4 * 2 * 2048;
+  const size_t lds_qds = ATT_DQDS_NSLOT * (AttCfg<HDP>::TILE + 8 * 2048);
   static bool attr = false;
   static bool dkdv4 = false;      // VITA_ATTN_DKDV4=1: the one-wave-per-SIMD dK/dV kernel (kept for A/B measurements)
   if (!attr) {
@@ -966,21 +1115,31 @@ static int launch_bwd(const void* qkv, const void* o, const void* dout, const fl
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv8_kernel<HDP, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv8);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<HDP, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<HDP, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_ds_kernel<HDP, NKS, ATT_DQDS_NSLOT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds_qds);
     attr = true;
   }
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((B * N + 3) / 4)), dim3(256), 0, s, (const uint16_t*)o, (const uint16_t*)dout,
                      lse, delta, B * N, (int)N, (int)H, HDP);
   VITA_CHECK_LAUNCH("vita_attn_bwd(delta)");
   dim3 grid((unsigned)((N + 127) / 128), (unsigned)H, (unsigned)B);
+  const int QT = (int)att_qt(N), KTP = (int)att_ktp(N);
+  const bool handoff = ws != nullptr && !dkdv4;     // dS tiles through HBM: dQ without the S / dP recompute
   if (dkdv4)
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDP, NKS>), grid, dim3(256), lds_kv, s, (const uint16_t*)qkv, (const uint16_t*)dout, lse,
                        delta, (uint16_t*)dqkv, (int)N, (int)H, scale);
   else
     hipLaunchKernelGGL((attn_bwd_dkdv8_kernel<HDP, NKS>), grid, dim3(512), lds_kv8, s, (const uint16_t*)qkv, (const uint16_t*)dout,
-                       delta, (uint16_t*)dqkv, (int)N, (int)H, scale);
+                       delta, (uint16_t*)dqkv, handoff ? (uint16_t*)ws : (uint16_t*)nullptr, QT, KTP, (int)N, (int)H, scale);
   VITA_CHECK_LAUNCH("vita_attn_bwd(dkdv)");
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, NKS>), grid, dim3(256), lds_q, s, (const uint16_t*)qkv, (const uint16_t*)dout, lse, delta,
-                     (uint16_t*)dqkv, (int)N, (int)H, scale);
+  if (handoff) {
+    dim3 gq((unsigned)((N + 255) / 256), (unsigned)H, (unsigned)B);
+    hipLaunchKernelGGL((attn_bwd_dq_ds_kernel<HDP, NKS, ATT_DQDS_NSLOT>), gq, dim3(512), lds_qds, s, (const uint16_t*)qkv,
+                       (const uint16_t*)ws, (uint16_t*)dqkv, QT, KTP, (int)N, (int)H, scale);
+  } else {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, NKS>), grid, dim3(256), lds_q, s, (const uint16_t*)qkv, (const uint16_t*)dout, lse, delta,
+                       (uint16_t*)dqkv, (int)N, (int)H, scale);
+  }
   VITA_CHECK_LAUNCH("vita_attn_bwd(dq)");
   return VITA_OK;
 }
@@ -1010,14 +1169,22 @@ extern "C" int vita_attn_fwd(const void* qkv, void* o, float* lse, int64_t B, in
   return VITA_ERR_UNSUPPORTED;
 }
 
+extern "C" int64_t vita_attn_bwd_ws_bytes(int64_t B, int64_t N, int64_t H) {
+  if (B <= 0 || N <= 0 || H <= 0) return 0;
+  return B * H * att_ktp(N) * att_qt(N) * 2048;
+}
+
 extern "C" int vita_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv,
-                             int64_t B, int64_t N, int64_t H, int64_t hd, int64_t hdp, float scale, void* stream) {
+                             void* ws, int64_t ws_bytes, int64_t B, int64_t N, int64_t H, int64_t hd, int64_t hdp, float scale,
+                             void* stream) {
   VITA_REQUIRE(qkv && o && dout && lse && delta && dqkv && B > 0 && N > 0 && H > 0 && B < 65536 && H < 65536);
-  VITA_REQUIRE((((uintptr_t)qkv | (uintptr_t)dout | (uintptr_t)dqkv | (uintptr_t)o) & 15) == 0);
+  VITA_REQUIRE((((uintptr_t)qkv | (uintptr_t)dout | (uintptr_t)dqkv | (uintptr_t)o | (uintptr_t)ws) & 15) == 0);
   VITA_REQUIRE((N + 64) * 3 * H * hdp * 2 < (int64_t)0xffffffffll);
+  VITA_REQUIRE(ws == nullptr || ws_bytes >= vita_attn_bwd_ws_bytes(B, N, H));
+  VITA_REQUIRE(ws == nullptr || att_ktp(N) * att_qt(N) * 2048 < (int64_t)0xfffffff0ll);      // one head's tiles behind one descriptor
   hipStream_t s = (hipStream_t)stream;
   const int64_t nks = (hd + 15) / 16;
-#define BWD_CALL(A, K) launch_bwd<A, K>(qkv, o, dout, lse, delta, dqkv, B, N, H, scale, s)
+#define BWD_CALL(A, K) launch_bwd<A, K>(qkv, o, dout, lse, delta, dqkv, ws, B, N, H, scale, s)
   ATT_DISPATCH(BWD_CALL)
 #undef BWD_CALL
   vita_set_error("vita_attn_bwd: unsupported head dim", hipSuccess);
