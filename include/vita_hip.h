@@ -177,10 +177,12 @@ int vita_attn_fwd(const void* qkv, void* o, float* lse, int64_t B, int64_t N, in
 /* backward: recomputes P from q, k and lse; deterministic (no atomics).  dout bf16 [B][N][H][hdp];
  * delta fp32 [B][H][2][N] scratch (written here: a copy of lse and rowsum(dout*o)); dqkv bf16 like qkv, every element of
  * the three parts is written (pads zero).
- * ws (optional, 16-byte aligned, ws_bytes >= vita_attn_bwd_ws_bytes(B, N, H) = B*H*N^2*2 B rounded up to tiles):
- * scratch through which the dK/dV kernel hands its bf16 dS tiles to a streaming dQ kernel, so dQ costs one
- * product instead of three; with ws == NULL the dQ kernel recomputes S and dP itself (no extra memory). */
-int64_t vita_attn_bwd_ws_bytes(int64_t B, int64_t N, int64_t H);
+ * ws (optional, 16-byte aligned, ws_bytes >= vita_attn_bwd_ws_bytes(B, N, H, hdp) = B*H*N^2*2 B rounded up to
+ * tiles + a fixed 0.23 MB * hdp): scratch through which the dK/dV kernel hands its bf16 dS tiles to a streaming dQ
+ * kernel, so dQ costs one product instead of three, and in which the workgroups of a partly filled last round leave
+ * fp32 partial dK/dV (summed in a fixed order); with ws == NULL the dQ kernel recomputes S and dP itself and the
+ * dK/dV grid is launched whole (no extra memory). */
+int64_t vita_attn_bwd_ws_bytes(int64_t B, int64_t N, int64_t H, int64_t hdp);
 int vita_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta,
                   void* dqkv, void* ws, int64_t ws_bytes, int64_t B, int64_t N, int64_t H, int64_t hd,
                   int64_t hdp, float scale, void* stream);

@@ -57,7 +57,7 @@ SIGNATURES = {
     "vita_sigmoid_mse_patch": [vp, i64, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, f32, vp, vp, vp, i64, vp],
     "vita_attn_supported": [i64, i64],
     "vita_attn_fwd": [vp, vp, vp, i64, i64, i64, i64, i64, f32, vp],
-    "vita_attn_bwd_ws_bytes": [i64, i64, i64],
+    "vita_attn_bwd_ws_bytes": [i64, i64, i64, i64],
     "vita_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, f32, vp],
     "vita_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, i64, vp],
     "vita_cine_partial_floats": [i64],

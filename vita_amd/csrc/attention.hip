@@ -607,7 +607,8 @@ template <int HDP, int NKS>
 __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                              const float* __restrict__ delta, uint16_t* __restrict__ dqkv,
                                                              uint16_t* __restrict__ ds_out, int QT, int KTP,
-                                                             int N, int H, float scale) {
+                                                             float* __restrict__ part, int wg_base, int nsplit,
+                                                             int tiles_per_split, int N, int H, float scale) {
   using C = AttCfg<HDP>;
   constexpr int NDT = C::NDT, TILE = C::TILE, BUF = 2 * TILE, NSLOT = ATT_BWD_NSLOT;
   constexpr int NI = 32 / C::RPI / 8, DPT = 2 * NI;     // DMA pieces per wave per image / per tile
@@ -616,7 +617,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int role = wave >> 2, kb = wave & 3;
-  const int h = blockIdx.y, b = blockIdx.z;
+  // 1-D grid over (batch, head, 128-key block) x nsplit query ranges.  nsplit > 1 only in the tail launch (the last,
+  // partly filled round of workgroups): each workgroup then sweeps tiles [t0, t1) of the queries and leaves fp32
+  // partial dK / dV in `part`, summed in a fixed order by attn_bwd_tail_reduce_kernel.
+  const int KB = (N + 127) >> 7;
+  const int lin = wg_base + (int)blockIdx.x / nsplit, sp = (int)blockIdx.x % nsplit;
+  const int bx = lin % KB, h = (lin / KB) % H, b = lin / (KB * H);
   const int64_t ld = 3ll * H * HDP, ldo = (int64_t)H * HDP;
   const uint16_t* base = qkv + (int64_t)b * N * ld;
   const uint32_t extent = (uint32_t)((((int64_t)N - 1) * ld + HDP) * 2);
@@ -629,7 +635,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
 
   lds_zero<HDP>(smem, XB + 4 * 2 * 2048, tid);
   const int lk = lane & 31, hh = lane >> 5;
-  const int key = blockIdx.x * 128 + kb * 32 + lk;
+  const int key = bx * 128 + kb * 32 + lk;
   bf16x8 frag[NKS];
 #pragma unroll
   for (int s = 0; s < NKS; ++s)
@@ -642,20 +648,24 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   const float c_exp2 = scale * 1.4426950408889634f;
   const int ntiles = (N + 31) / 32;
+  const int t0 = sp * tiles_per_split;
+  const int t1 = t0 + tiles_per_split < ntiles ? t0 + tiles_per_split : ntiles;
+  const int nt = t1 - t0;                               // tiles of this workgroup: absolute tile = t0 + local index
 
   DmaOff<HDP, 8> offq, offo;
   offq.init(ld, wave, lane);
   offo.init(ldo, wave, lane);
-  auto issue_piece = [&](int tile, int buf, int p) {
+  auto issue_piece = [&](int tile_local, int buf, int p) {
     char* bp = smem + buf * BUF;
-    const int tcl = tile < ntiles ? tile : ntiles;      // tiles past the end: every row out of range, reads zeros
+    const int tile = t0 + tile_local;
+    const int tcl = tile < t1 ? tile : ntiles;          // tiles past the end of the range: every row out of range, reads zeros
     if (p < NI) offq.issue(rsQ, (uint32_t)tcl * (uint32_t)(32 * ld * 2), bp, wave, p);
     else if (p < 2 * NI) offo.issue(rsDO, (uint32_t)tcl * (uint32_t)(32 * ldo * 2), bp + TILE, wave, p - NI);
     else if (wave0) {
       typedef __attribute__((address_space(3))) void lds_void;
       lds_void* dst = (lds_void*)(smem + LC + buf * 256);
       const int qq = tile * 32 + (lane & 31);
-      const uint32_t voff = (uint32_t)(qq < N ? (lane < 32 ? qq : N + qq) : 2 * N) * 4;
+      const uint32_t voff = (uint32_t)(tile < t1 && qq < N ? (lane < 32 ? qq : N + qq) : 2 * N) * 4;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL, dst, 4, voff, 0, 0, 0);
     }
   };
@@ -698,7 +708,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
   if (role == 0) {
     // step t: S chain of tile t (+ DMA of tile t+2), P(t) -> partner, dV^T += dO^T(t) P(t)
     int slot = 0;
-    for (int t = 0; t <= ntiles; ++t) {
+    for (int t = 0; t <= nt; ++t) {
       const int pre = slot >= 2 ? slot - 2 : slot + NSLOT - 2;      // slot of tile t+2 = slot of tile t-2
       f32x16 sacc;
 #pragma unroll
@@ -734,7 +744,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
     // dS hand-off to attn_bwd_dq_ds_kernel: tile (key block kt, query tile qt) = dS^T[32 keys][32 queries] bf16, 2 KiB,
     // at ((bh * KTP + kt) * QT + qt) * 2 KiB; inside a tile byte = key*64 + hh*32 + rr*8 + j*2 for query 8rr + 4hh + j,
     // i.e. every lane's eight packed words are 32 contiguous bytes and a wave writes its tile as one contiguous 2 KiB.
-    const int kt = blockIdx.x * 4 + kb;
+    const int kt = bx * 4 + kb;
     const bool ds_store = ds_out != nullptr && __builtin_amdgcn_readfirstlane(kt * 32) < N;
     // one descriptor (SGPRs) per (head, key block) row of tiles + one 32-bit lane offset: no 64-bit pointer in VGPRs
     const __amdgpu_buffer_rsrc_t rsS = mk_rsrc(ds_out + (((int64_t)b * H + h) * KTP + kt) * QT * 1024, (uint32_t)QT * 2048u);
@@ -742,7 +752,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
     f32x16 dpacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dpacc[r] = 0.f;
-    for (int t = 0; t <= ntiles; ++t) {
+    for (int t = 0; t <= nt; ++t) {
       const int pre = slot >= 2 ? slot - 2 : slot + NSLOT - 2;
       const int prv = slot >= 1 ? slot - 1 : NSLOT - 1;              // slot of tile t-1
       const float* ds_ = reinterpret_cast<const float*>(smem + LC + prv * 256 + 128);
@@ -759,7 +769,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
         dw[2 * rr + 1] = cvt_pk(p2 * (dpacc[4 * rr + 2] - d4[2]), p3 * (dpacc[4 * rr + 3] - d4[3]));
       }
       if (ds_store && t >= 1) {       // dS^T of tile t-1, exactly the bf16 values the dK product consumes
-        const uint32_t toff = (uint32_t)(t - 1) * 2048u;      // wave-uniform
+        const uint32_t toff = (uint32_t)(t0 + t - 1) * 2048u;      // wave-uniform
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{dw[0], dw[1], dw[2], dw[3]}, rsS, ds_lane, toff, 2);       // aux 2 = nt
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{dw[4], dw[5], dw[6], dw[7]}, rsS, ds_lane + 16, toff, 2);
       }
@@ -779,9 +789,18 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
     }
   }
   dma_wait();      // the zero-filled prefetches past the last tile must land before the LDS is released
-  if (key < N) {
+  const float f = role ? scale : 1.f;
+  if (part != nullptr) {
+    // part[(tail workgroup * nsplit + split)][dV | dK][128 keys][HDP] fp32
+    float* prow = part + ((((int64_t)(lin - wg_base) * nsplit + sp) * 2 + role) * 128 + kb * 32 + lk) * HDP;
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        *reinterpret_cast<f32x4*>(prow + i * 32 + 8 * rr + 4 * hh) =
+            f32x4{acc[i][4 * rr] * f, acc[i][4 * rr + 1] * f, acc[i][4 * rr + 2] * f, acc[i][4 * rr + 3] * f};
+  } else if (key < N) {
     uint16_t* row = dqkv + ((int64_t)b * N + key) * ld + ((2 - role) * H + h) * HDP;     // S role -> dV, dP role -> dK
-    const float f = role ? scale : 1.f;
 #pragma unroll
     for (int i = 0; i < NDT; ++i)
 #pragma unroll
@@ -791,6 +810,24 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
                                                     cvt_pk(acc[i][4 * rr + 2] * f, acc[i][4 * rr + 3] * f)};
       }
   }
+}
+
+// dK / dV of the tail workgroups: sum the nsplit fp32 partials in split order (deterministic) and write bf16
+__global__ __launch_bounds__(256) void attn_bwd_tail_reduce_kernel(const float* __restrict__ part, uint16_t* __restrict__ dqkv,
+                                                                   int wg_base, int nwg, int nsplit, int N, int H, int HDP) {
+  const int c4 = HDP / 4;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)nwg * 2 * 128 * c4) return;
+  const int c = (int)(idx % c4), kk = (int)((idx / c4) % 128), role = (int)((idx / (c4 * 128)) % 2), w = (int)(idx / (c4 * 256));
+  const int KB = (N + 127) >> 7, lin = wg_base + w;
+  const int bx = lin % KB, h = (lin / KB) % H, b = lin / (KB * H);
+  const int key = bx * 128 + kk;
+  if (key >= N) return;
+  f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < nsplit; ++s)
+    a += *reinterpret_cast<const f32x4*>(part + ((((int64_t)w * nsplit + s) * 2 + role) * 128 + kk) * HDP + c * 4);
+  uint16_t* row = dqkv + ((int64_t)b * N + key) * (3ll * H * HDP) + ((2 - role) * H + h) * HDP + c * 4;
+  *reinterpret_cast<u32x2*>(row) = u32x2{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3])};
 }
 
 template <int HDP, int NKS>
@@ -1068,7 +1105,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_ds_kernel(const uint16_t* 
   template __global__ void attn_bwd_dkdv_kernel<A, K>(const uint16_t*, const uint16_t*, const float*, const float*,  \
                                                       uint16_t*, int, int, float);                                   \
   template __global__ void attn_bwd_dkdv8_kernel<A, K>(const uint16_t*, const uint16_t*, const float*, uint16_t*, uint16_t*, \
-                                                       int, int, int, int, float);                                   \
+                                                       int, int, float*, int, int, int, int, int, float);            \
   template __global__ void attn_bwd_dq_ds_kernel<A, K, ATT_DQDS_NSLOT>(const uint16_t*, const uint16_t*, uint16_t*, int,   \
                                                                        int, int, int, float);                        \
   template __global__ void attn_bwd_dq_kernel<A, K>(const uint16_t*, const uint16_t*, const float*, const float*,    \
@@ -1100,6 +1137,32 @@ static int launch_fwd(const void* qkv, void* o, float* lse, int64_t B, int64_t N
 // dS hand-off geometry: query tiles QT = ceil(N/32), key blocks padded to the dK/dV grid KTP = 4 * ceil(N/128)
 static inline int64_t att_qt(int64_t N) { return (N + 31) / 32; }
 static inline int64_t att_ktp(int64_t N) { return 4 * ((N + 127) / 128); }
+// workspace = [ fp32 partial dK/dV of the tail workgroups (fixed upper bound) | bf16 dS tiles ]
+#define ATT_MAX_CU 320
+static inline int64_t att_part_bytes(int64_t hdp) { return (int64_t)ATT_MAX_CU * 2 * 128 * hdp * 4; }
+static int att_num_cu() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    n = v > ATT_MAX_CU ? ATT_MAX_CU : v;
+  }
+  return n;
+}
+// The dK/dV grid runs one 8-wave workgroup per CU, every workgroup takes the same time, so a grid of L workgroups
+// costs ceil(L / CUs) rounds.  When the last round is less than 3/4 full its `rem` workgroups are launched
+// separately with their query sweep cut into nsplit ranges (rem * nsplit <= CUs, >= 8 tiles per range).
+static void att_tail_plan(int64_t L, int64_t ntiles, int ncu, int64_t* l_main, int* nsplit, int* tiles_per_split) {
+  *l_main = L; *nsplit = 1; *tiles_per_split = (int)ntiles;
+  const int64_t rem = L % ncu;
+  if (rem == 0 || rem * 4 > (int64_t)ncu * 3) return;
+  int64_t ns = ncu / rem;
+  if (ns > ntiles / 8) ns = ntiles / 8;
+  if (ns < 2) return;
+  const int64_t per = (ntiles + ns - 1) / ns;
+  *l_main = L - rem; *nsplit = (int)((ntiles + per - 1) / per); *tiles_per_split = (int)per;
+}
 
 template <int HDP, int NKS>
 static int launch_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, void* ws,
@@ -1109,9 +1172,12 @@ static int launch_bwd(const void* qkv, const void* o, const void* dout, const fl
   const size_t lds_qds = ATT_DQDS_NSLOT * (AttCfg<HDP>::TILE + 8 * 2048);
   static bool attr = false;
   static bool dkdv4 = false;      // VITA_ATTN_DKDV4=1: the one-wave-per-SIMD dK/dV kernel (kept for A/B measurements)
+  static bool no_tail = false;    // VITA_ATTN_NO_TAIL_SPLIT=1: A/B switch of the tail launch
   if (!attr) {
     const char* e = getenv("VITA_ATTN_DKDV4");
     dkdv4 = e && e[0] == '1';
+    e = getenv("VITA_ATTN_NO_TAIL_SPLIT");
+    no_tail = e && e[0] == '1';
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv8_kernel<HDP, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv8);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<HDP, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<HDP, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
@@ -1125,17 +1191,32 @@ static int launch_bwd(const void* qkv, const void* o, const void* dout, const fl
   dim3 grid((unsigned)((N + 127) / 128), (unsigned)H, (unsigned)B);
   const int QT = (int)att_qt(N), KTP = (int)att_ktp(N);
   const bool handoff = ws != nullptr && !dkdv4;     // dS tiles through HBM: dQ without the S / dP recompute
-  if (dkdv4)
+  if (dkdv4) {
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDP, NKS>), grid, dim3(256), lds_kv, s, (const uint16_t*)qkv, (const uint16_t*)dout, lse,
                        delta, (uint16_t*)dqkv, (int)N, (int)H, scale);
-  else
-    hipLaunchKernelGGL((attn_bwd_dkdv8_kernel<HDP, NKS>), grid, dim3(512), lds_kv8, s, (const uint16_t*)qkv, (const uint16_t*)dout,
-                       delta, (uint16_t*)dqkv, handoff ? (uint16_t*)ws : (uint16_t*)nullptr, QT, KTP, (int)N, (int)H, scale);
+  } else {
+    float* part = (float*)ws;
+    uint16_t* dsb = handoff ? (uint16_t*)((char*)ws + att_part_bytes(HDP)) : (uint16_t*)nullptr;
+    const int64_t L = B * H * ((N + 127) / 128);
+    int64_t l_main = L; int nsplit = 1, per = QT;
+    if (ws != nullptr && !no_tail) att_tail_plan(L, QT, att_num_cu(), &l_main, &nsplit, &per);
+    if (l_main > 0)
+      hipLaunchKernelGGL((attn_bwd_dkdv8_kernel<HDP, NKS>), dim3((unsigned)l_main), dim3(512), lds_kv8, s, (const uint16_t*)qkv,
+                         (const uint16_t*)dout, delta, (uint16_t*)dqkv, dsb, QT, KTP, (float*)nullptr, 0, 1, QT, (int)N, (int)H, scale);
+    if (l_main < L) {
+      const int nwg = (int)(L - l_main);
+      hipLaunchKernelGGL((attn_bwd_dkdv8_kernel<HDP, NKS>), dim3((unsigned)(nwg * nsplit)), dim3(512), lds_kv8, s, (const uint16_t*)qkv,
+                         (const uint16_t*)dout, delta, (uint16_t*)dqkv, dsb, QT, KTP, part, (int)l_main, nsplit, per, (int)N, (int)H, scale);
+      const int64_t nthr = (int64_t)nwg * 2 * 128 * (HDP / 4);
+      hipLaunchKernelGGL(attn_bwd_tail_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (const float*)part,
+                         (uint16_t*)dqkv, (int)l_main, nwg, nsplit, (int)N, (int)H, HDP);
+    }
+  }
   VITA_CHECK_LAUNCH("vita_attn_bwd(dkdv)");
   if (handoff) {
     dim3 gq((unsigned)((N + 255) / 256), (unsigned)H, (unsigned)B);
     hipLaunchKernelGGL((attn_bwd_dq_ds_kernel<HDP, NKS, ATT_DQDS_NSLOT>), gq, dim3(512), lds_qds, s, (const uint16_t*)qkv,
-                       (const uint16_t*)ws, (uint16_t*)dqkv, QT, KTP, (int)N, (int)H, scale);
+                       (const uint16_t*)((char*)ws + att_part_bytes(HDP)), (uint16_t*)dqkv, QT, KTP, (int)N, (int)H, scale);
   } else {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, NKS>), grid, dim3(256), lds_q, s, (const uint16_t*)qkv, (const uint16_t*)dout, lse, delta,
                        (uint16_t*)dqkv, (int)N, (int)H, scale);
@@ -1169,9 +1250,9 @@ extern "C" int vita_attn_fwd(const void* qkv, void* o, float* lse, int64_t B, in
   return VITA_ERR_UNSUPPORTED;
 }
 
-extern "C" int64_t vita_attn_bwd_ws_bytes(int64_t B, int64_t N, int64_t H) {
-  if (B <= 0 || N <= 0 || H <= 0) return 0;
-  return B * H * att_ktp(N) * att_qt(N) * 2048;
+extern "C" int64_t vita_attn_bwd_ws_bytes(int64_t B, int64_t N, int64_t H, int64_t hdp) {
+  if (B <= 0 || N <= 0 || H <= 0 || hdp <= 0) return 0;
+  return att_part_bytes(hdp) + B * H * att_ktp(N) * att_qt(N) * 2048;
 }
 
 extern "C" int vita_attn_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv,
@@ -1180,7 +1261,7 @@ extern "C" int vita_attn_bwd(const void* qkv, const void* o, const void* dout, c
   VITA_REQUIRE(qkv && o && dout && lse && delta && dqkv && B > 0 && N > 0 && H > 0 && B < 65536 && H < 65536);
   VITA_REQUIRE((((uintptr_t)qkv | (uintptr_t)dout | (uintptr_t)dqkv | (uintptr_t)o | (uintptr_t)ws) & 15) == 0);
   VITA_REQUIRE((N + 64) * 3 * H * hdp * 2 < (int64_t)0xffffffffll);
-  VITA_REQUIRE(ws == nullptr || ws_bytes >= vita_attn_bwd_ws_bytes(B, N, H));
+  VITA_REQUIRE(ws == nullptr || ws_bytes >= vita_attn_bwd_ws_bytes(B, N, H, hdp));
   VITA_REQUIRE(ws == nullptr || att_ktp(N) * att_qt(N) * 2048 < (int64_t)0xfffffff0ll);      // one head's tiles behind one descriptor
   hipStream_t s = (hipStream_t)stream;
   const int64_t nks = (hd + 15) / 16;

@@ -166,19 +166,29 @@ __global__ __launch_bounds__(256, 3) void ln_bwd_kernel(const void* __restrict__
 }
 
 // 64 columns x 4 row groups per block
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblk, int d, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta) {
-  __shared__ float red[2][4][64];
+// grid (ceil(d/64), 2): blockIdx.y = 0 sums the dgamma partials, 1 the dbeta partials; 16 waves take interleaved
+// partial rows with four independent accumulators each (the 2 x nblk x d fp32 partials are L2-resident)
+__global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblk, int d, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta) {
+  __shared__ float red[16][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cx;
-  float a = 0.f, b = 0.f;
-  if (c < d)
-    for (int k = ry; k < nblk; k += 4) { a += partial[(int64_t)k * d + c]; b += partial[((int64_t)nblk + k) * d + c]; }
-  red[0][ry][cx] = a; red[1][ry][cx] = b;
+  const float* p = partial + (int64_t)blockIdx.y * nblk * d + c;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (c < d) {
+    int k = ry;
+    for (; k + 48 < nblk; k += 64) {
+      a0 += p[(int64_t)k * d]; a1 += p[(int64_t)(k + 16) * d]; a2 += p[(int64_t)(k + 32) * d]; a3 += p[(int64_t)(k + 48) * d];
+    }
+    for (; k < nblk; k += 16) a0 += p[(int64_t)k * d];
+  }
+  red[ry][cx] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (ry == 0 && c < d) {
-    dgamma[c] = red[0][0][cx] + red[0][1][cx] + red[0][2][cx] + red[0][3][cx];
-    dbeta[c] = red[1][0][cx] + red[1][1][cx] + red[1][2][cx] + red[1][3][cx];
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += red[w][cx];
+    (blockIdx.y ? dbeta : dgamma)[c] = t;
   }
 }
 
@@ -202,7 +212,7 @@ extern "C" int vita_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype
   else LN_BWD_LAUNCH(8);
 #undef LN_BWD_LAUNCH
   VITA_CHECK_LAUNCH("vita_layernorm_bwd");
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((d + 63) / 64)), dim3(256), 0, (hipStream_t)stream, partial,
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((d + 63) / 64), 2), dim3(1024), 0, (hipStream_t)stream, partial,
                      nblk, (int)d, dgamma, dbeta);
   VITA_CHECK_LAUNCH("vita_layernorm_bwd_reduce");
   return VITA_OK;
@@ -485,8 +495,10 @@ extern "C" int vita_colsum(const void* x, int32_t dtype, int64_t ld, int64_t row
   VITA_REQUIRE(((uintptr_t)x & 15) == 0);
   if (hipMemsetAsync(out, 0, cols * sizeof(float), (hipStream_t)stream) != hipSuccess) return VITA_ERR_LAUNCH;
   const int64_t colblk = (cols + 64 * cpt - 1) / (64 * cpt);
-  // about 2048 blocks in all, at least 64 rows per block
+  // about 2048 blocks in all, at least 64 rows per block, at most 256 row chunks: every chunk ends in one fp32 atomic
+  // per column, and a narrow matrix (few column blocks) otherwise spends its time serialising them
   int64_t chunks = (2048 + colblk - 1) / colblk;
+  if (chunks > 256) chunks = 256;
   if (chunks > (rows + 63) / 64) chunks = (rows + 63) / 64;
   if (chunks < 1) chunks = 1;
   const int64_t rpb = (rows + chunks - 1) / chunks;

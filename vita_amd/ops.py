@@ -256,7 +256,7 @@ def attn_bwd(qkv, o, do, lse, dqkv, B, N, H, hd, hdp, scale, handoff=None):
     delta = torch.empty(B, H, 2, N, dtype=torch.float32, device=qkv.device)   # [lse | rowsum(dO*O)] scratch
     ws, ws_bytes = None, 0
     if ATTN_DS_HANDOFF if handoff is None else handoff:
-        ws_bytes = _lib.lib().vita_attn_bwd_ws_bytes(B, N, H)
+        ws_bytes = _lib.lib().vita_attn_bwd_ws_bytes(B, N, H, hdp)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device)
     with _Timed("attn_bwd_kernels", 10.0 * B * H * N * N * hd):
         check(_lib.lib().vita_attn_bwd(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), delta.data_ptr(),
