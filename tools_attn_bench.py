@@ -40,6 +40,21 @@ def colsum(rows, cols):
     t = timeit(lambda: ops.colsum(x, cols, rows, cols), 10)
     print(f"colsum {rows}x{cols}: {t*1e3:.1f} us ({rows*cols*2/t/1e6:.0f} GB/s)", flush=True)
 
+def scatter_mse():
+    B, L, keep, D = 2, 23040, 6912, 1025
+    ld = ops.rup(D, 64)
+    dout = torch.randn(B, L + 1, ld, device="cuda")
+    ids = torch.stack([torch.randperm(L, device="cuda") for _ in range(B)])
+    ids = torch.cat([torch.zeros(B, 1, dtype=torch.int64, device="cuda"), ids + 1], 1)      # decoder un-shuffle with the cls row
+    t = timeit(lambda: ops.row_scatter(dout, ld, L + 1, ids, L + 1, keep + 1, B, D, ld, want_dfill=True), 10)
+    print(f"row_scatter {B}x{L+1}x{D}: {t*1e3:.1f} us", flush=True)
+    img = torch.rand(B, 9, 50, 128, 128, device="cuda")
+    z = torch.randn(B * (L + 1), 328, device="cuda")
+    loss = torch.zeros(1, device="cuda"); dz = torch.empty(B * (L + 1), 328, dtype=torch.bfloat16, device="cuda")
+    t = timeit(lambda: ops.sigmoid_mse_patch(z, 328, img, (5, 8, 8), None, 1.0 / (B * L * 320), loss, dz=dz, ld_dz=328), 10)
+    print(f"sigmoid_mse_patch: {t*1e3:.1f} us", flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     hand = [bool(int(sys.argv[2]))] if len(sys.argv) > 2 else [True, False]
@@ -47,6 +62,8 @@ if __name__ == "__main__":
         ln(13826); ln(46082)
         for r in (13826, 46082):
             for c in (1088, 3360, 4160): colsum(r, c)
+    if which in ("all", "row"):
+        scatter_mse()
     if which in ("all", "attn"):
         for h in hand:
             attn(2, 6913, handoff=h); attn(2, 23041, handoff=h)

@@ -132,45 +132,52 @@ extern "C" int vita_ce_rows(const float* logits, int64_t ld, int64_t rows, int64
 }
 
 // ------------------------------------------------------------------------------------- sigmoid + MSE vs patchified image
+// one wave per row, a block walks rows blockIdx.x*4 + wave, + 4*gridDim.x, ...; the loss leaves one atomic per block
 __global__ __launch_bounds__(256) void sigmoid_mse_patch_kernel(const float* __restrict__ z, int64_t ldz, const float* __restrict__ img,
                                                                 int S, int T, int H, int W, int pt, int ph, int pw, int64_t L,
                                                                 const float* __restrict__ mask, float inv_count, float* __restrict__ pred,
                                                                 float* __restrict__ loss, uint16_t* __restrict__ dz, int64_t ld_dz,
                                                                 int64_t total_rows) {
-  const int lane = threadIdx.x & 63;
-  const int64_t rowi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // row in [0, nb*(1+L))
-  if (rowi >= total_rows) return;
-  const int64_t b = rowi / (L + 1), r = rowi % (L + 1);
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int P = pt * ph * pw;
-  if (r == 0) {   // cls row: no loss, zero gradient
-    if (dz) for (int e = lane; e < ld_dz; e += 64) dz[rowi * ld_dz + e] = 0;
-    return;
-  }
-  const int64_t id = r - 1;
   const int t = T / pt, h = H / ph, w = W / pw;
-  const int wi = (int)(id % w); int64_t q = id / w;
-  const int hi = (int)(q % h); q /= h;
-  const int ti = (int)(q % t); const int s = (int)(q / t);
-  const float* base = img + (((b * S + s) * T + (int64_t)ti * pt) * H + (int64_t)hi * ph) * W + (int64_t)wi * pw;
-  const float wrow = mask ? mask[b * L + id] : 1.f;
-  const float* zr = z + rowi * ldz;
-  float acc = 0.f;
   const int lim = dz ? (int)ld_dz : P;
-  for (int e = lane; e < lim; e += 64) {
-    float g = 0.f;
-    if (e < P) {
-      const int p_w = e % pw, p_h = (e / pw) % ph, p_t = e / (pw * ph);
-      const float tgt = base[((int64_t)p_t * H + p_h) * W + p_w];
-      const float pr = 1.f / (1.f + __expf(-zr[e]));
-      if (pred) pred[(b * L + id) * P + e] = pr;
-      const float diff = pr - tgt;
-      acc += diff * diff * wrow;
-      g = 2.f * diff * pr * (1.f - pr) * wrow * inv_count;
+  float acc = 0.f;
+  for (int64_t rowi = (int64_t)blockIdx.x * 4 + wave; rowi < total_rows; rowi += (int64_t)gridDim.x * 4) {   // row in [0, nb*(1+L))
+    const int64_t b = rowi / (L + 1), r = rowi % (L + 1);
+    if (r == 0) {   // cls row: no loss, zero gradient
+      if (dz) for (int e = lane; e < ld_dz; e += 64) dz[rowi * ld_dz + e] = 0;
+      continue;
     }
-    if (dz) dz[rowi * ld_dz + e] = f32_to_bf16_bits(g);
+    const int64_t id = r - 1;
+    const int wi = (int)(id % w); int64_t q = id / w;
+    const int hi = (int)(q % h); q /= h;
+    const int ti = (int)(q % t); const int s = (int)(q / t);
+    const float* base = img + (((b * S + s) * T + (int64_t)ti * pt) * H + (int64_t)hi * ph) * W + (int64_t)wi * pw;
+    const float wrow = mask ? mask[b * L + id] : 1.f;
+    const float* zr = z + rowi * ldz;
+    for (int e = lane; e < lim; e += 64) {
+      float g = 0.f;
+      if (e < P) {
+        const int p_w = e % pw, p_h = (e / pw) % ph, p_t = e / (pw * ph);
+        const float tgt = base[((int64_t)p_t * H + p_h) * W + p_w];
+        const float pr = 1.f / (1.f + __expf(-zr[e]));
+        if (pred) pred[(b * L + id) * P + e] = pr;
+        const float diff = pr - tgt;
+        acc += diff * diff * wrow;
+        g = 2.f * diff * pr * (1.f - pr) * wrow * inv_count;
+      }
+      if (dz) dz[rowi * ld_dz + e] = f32_to_bf16_bits(g);
+    }
   }
   acc = wave_sum(acc);
-  if (lane == 0 && acc != 0.f) atomicAdd(loss, acc * inv_count);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+    if (tot != 0.f) atomicAdd(loss, tot * inv_count);
+  }
 }
 extern "C" int vita_sigmoid_mse_patch(const float* z, int64_t ldz, const float* img, int64_t nb, int64_t S, int64_t T, int64_t H,
                                       int64_t W, int64_t pt, int64_t ph, int64_t pw, const float* mask, float inv_count,
@@ -180,7 +187,8 @@ extern "C" int vita_sigmoid_mse_patch(const float* z, int64_t ldz, const float* 
   VITA_REQUIRE(ldz >= P);
   if (dz_bf16) VITA_REQUIRE(ld_dz >= P);
   const int64_t total = nb * (L + 1);
-  hipLaunchKernelGGL(sigmoid_mse_patch_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, z, ldz, img, (int)S,
+  const int64_t nblk = (total + 3) / 4 < 2048 ? (total + 3) / 4 : 2048;
+  hipLaunchKernelGGL(sigmoid_mse_patch_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, z, ldz, img, (int)S,
                      (int)T, (int)H, (int)W, (int)pt, (int)ph, (int)pw, L, mask, inv_count, pred, loss, (uint16_t*)dz_bf16, ld_dz, total);
   VITA_CHECK_LAUNCH("vita_sigmoid_mse_patch");
   return VITA_OK;

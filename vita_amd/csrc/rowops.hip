@@ -13,6 +13,7 @@ extern "C" int vita_version(void) { return 100; }
 
 // ------------------------------------------------------------------------------------- LayerNorm
 #define LN_MAXV 8   // float4 per lane -> d <= 2048
+template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      void* __restrict__ y, int64_t ldy, int y_f32,
@@ -22,10 +23,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const float* xr = x + row * ldx;
-  f32x4 v[LN_MAXV];
+  f32x4 v[NV];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
     v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (c < d) {
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   const float mu = wave_sum(s) / (float)d;
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
 #pragma unroll
     for (int r = 0; r < 4; ++r) if (c + r < d) { const float t = v[i][r] - mu; q += t * t; }
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   const float rs = rsqrtf(wave_sum(q) / (float)d + eps);
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
     if (c >= ldy) continue;
     float o[4];
@@ -63,8 +64,14 @@ extern "C" int vita_layernorm_fwd(const float* x, int64_t ldx, const float* gamm
   VITA_REQUIRE(rows > 0 && d > 0 && d <= LN_MAXV * 256 && ldy <= LN_MAXV * 256);
   VITA_REQUIRE(ldx % 4 == 0 && ldx >= ((d + 3) / 4) * 4 && ldy % 4 == 0 && ldy >= d);
   VITA_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0);
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma,
-                     beta, y, ldy, y_dtype == VITA_DT_F32, mean, rstd, rows, (int)d, eps);
+  const int64_t width = ldy > d ? ldy : d;
+#define LN_FWD_LAUNCH(NV)                                                                                                     \
+  hipLaunchKernelGGL(ln_fwd_kernel<NV>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, \
+                     beta, y, ldy, y_dtype == VITA_DT_F32, mean, rstd, rows, (int)d, eps)
+  if (width <= 512) LN_FWD_LAUNCH(2);
+  else if (width <= 1280) LN_FWD_LAUNCH(5);
+  else LN_FWD_LAUNCH(8);
+#undef LN_FWD_LAUNCH
   VITA_CHECK_LAUNCH("vita_layernorm_fwd");
   return VITA_OK;
 }
@@ -99,8 +106,15 @@ __global__ __launch_bounds__(256, 3) void ln_bwd_kernel(const void* __restrict__
   const float inv_d = 1.f / (float)d;
   for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)nblk * 4) {
     const float mu = mean[row], rs = rstd[row];
-    f32x4 xh[NV], dyv[NV];
+    f32x4 xh[NV], dyv[NV], din[NV];
     float s1 = 0.f, s2 = 0.f;
+    // the residual gradient is fetched with x and dy (one memory latency per row, not two)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      din[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (dx_in && c < d) din[i] = *reinterpret_cast<const f32x4*>(dx_in + row * lddx + c);
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
@@ -139,7 +153,7 @@ __global__ __launch_bounds__(256, 3) void ln_bwd_kernel(const void* __restrict__
 #pragma unroll
           for (int r = 0; r < 4; ++r) if (c + r >= d) o[r] = 0.f;
         }
-        if (dx_in) o += *reinterpret_cast<const f32x4*>(dx_in + row * lddx + c);
+        o += din[i];
       }
       *reinterpret_cast<f32x4*>(dx_out + row * lddx + c) = o;
       if (dxb && c < ld_dxb)
@@ -308,33 +322,60 @@ extern "C" int vita_row_gather_f32(const float* x, int64_t ldx, int64_t l_in, co
   return VITA_OK;
 }
 
-__global__ __launch_bounds__(256) void row_scatter_kernel(const float* __restrict__ dout, int64_t ldo, int64_t l_out,
-                                                          const int64_t* __restrict__ ids, int64_t ld_ids,
-                                                          float* __restrict__ dx, int64_t ldx, int64_t l_in,
-                                                          float* __restrict__ dfill, int d) {
-  const int64_t j = blockIdx.x, b = blockIdx.y;
-  const int64_t dst = ids[b * ld_ids + j];
-  const float* s = dout + (b * l_out + j) * ldo;
-  if (dst < l_in) {
-    float* o = dx + (b * l_in + dst) * ldx;
-    for (int c = threadIdx.x * 4; c < ldx; c += 1024) {
-      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (c < d) { v = *reinterpret_cast<const f32x4*>(s + c);
+// One wave per row (16 waves per block, grid-stride over the rows of batch entry blockIdx.y): rows that map into dx are
+// copied with 16-B vectors; rows past l_in (the decoder's mask tokens) are summed per lane-owned column in registers,
+// reduced over the block's waves in LDS and leave ONE global atomic per column and block - a per-row atomicAdd would
+// serialise ~16k updates on each of the d addresses.
+#define SCATTER_NV 8     // float4 per lane -> d <= 2048
+__global__ __launch_bounds__(1024) void row_scatter_kernel(const float* __restrict__ dout, int64_t ldo, int64_t l_out,
+                                                           const int64_t* __restrict__ ids, int64_t ld_ids,
+                                                           float* __restrict__ dx, int64_t ldx, int64_t l_in,
+                                                           float* __restrict__ dfill, int d) {
+  __shared__ float red[SCATTER_NV * 256];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t b = blockIdx.y;
+  f32x4 fill[SCATTER_NV];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (c + r >= d) v[r] = 0.f; }
-      *reinterpret_cast<f32x4*>(o + c) = v;
+  for (int i = 0; i < SCATTER_NV; ++i) fill[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int c = threadIdx.x; c < SCATTER_NV * 256; c += 1024) red[c] = 0.f;
+  for (int64_t j = (int64_t)blockIdx.x * 16 + wave; j < l_out; j += (int64_t)gridDim.x * 16) {
+    const int64_t dst = ids[b * ld_ids + j];
+    const float* s = dout + (b * l_out + j) * ldo;
+    float* o = dst < l_in ? dx + (b * l_in + dst) * ldx : nullptr;
+#pragma unroll
+    for (int i = 0; i < SCATTER_NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if (c >= ldx) continue;
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < d) {
+        v = *reinterpret_cast<const f32x4*>(s + c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (c + r >= d) v[r] = 0.f;
+      }
+      if (o) *reinterpret_cast<f32x4*>(o + c) = v;
+      else fill[i] += v;
     }
-  } else if (dfill) {
-    for (int c = threadIdx.x; c < d; c += 256) atomicAdd(dfill + c, s[c]);
   }
+  if (dfill == nullptr) return;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < SCATTER_NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) if (c + r < d && fill[i][r] != 0.f) atomicAdd(&red[c + r], fill[i][r]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 1024) if (red[c] != 0.f) atomicAdd(dfill + c, red[c]);
 }
 extern "C" int vita_row_scatter_f32(const float* dout, int64_t ldo, int64_t l_out, const int64_t* ids, int64_t ld_ids,
                                     float* dx, int64_t ldx, int64_t l_in, float* dfill, int64_t nb, int64_t d,
                                     void* stream) {
   VITA_REQUIRE(dout && ids && dx && nb > 0 && nb < 65536 && l_out > 0 && d > 0);
-  VITA_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ldo >= ((d + 3) / 4) * 4 && ldx >= d);
+  VITA_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ldo >= ((d + 3) / 4) * 4 && ldx >= d && ldx <= SCATTER_NV * 256);
   VITA_REQUIRE(((uintptr_t)dx & 15) == 0 && ((uintptr_t)dout & 15) == 0);
-  hipLaunchKernelGGL(row_scatter_kernel, dim3((unsigned)l_out, (unsigned)nb), dim3(256), 0, (hipStream_t)stream, dout, ldo,
+  int64_t chunks = (512 + nb - 1) / nb;                 // about 512 blocks of 16 waves
+  if (chunks > (l_out + 15) / 16) chunks = (l_out + 15) / 16;
+  hipLaunchKernelGGL(row_scatter_kernel, dim3((unsigned)chunks, (unsigned)nb), dim3(1024), 0, (hipStream_t)stream, dout, ldo,
                      l_out, ids, ld_ids, dx, ldx, l_in, dfill, (int)d);
   VITA_CHECK_LAUNCH("vita_row_scatter_f32");
   return VITA_OK;
