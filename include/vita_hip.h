@@ -156,6 +156,9 @@ int vita_cast_f32_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_
 /* column sums of a bf16 or fp32 matrix [rows][ld] -> fp32 out[cols] (bias gradients) */
 int vita_colsum(const void* x, int32_t dtype, int64_t ld, int64_t rows, int64_t cols, float* out,
                 void* stream);
+/* same, ADDED to out (fp32 atomics): bias gradients accumulated straight into an optimizer's gradient buffer */
+int vita_colsum_acc(const void* x, int32_t dtype, int64_t ld, int64_t rows, int64_t cols, float* out,
+                    void* stream);
 /* materialised attention (first correct path; timm Attention.forward):
  * p = softmax(scale * s) row-wise.  s fp32 [nrows_total][lds], p bf16 [..][ldp]; columns
  * [n, ldp) of p are written as zero. */

@@ -48,6 +48,7 @@ SIGNATURES = {
     "vita_tokens_assemble": [vp, i64, vp, vp, vp, i64, i64, i64, vp, i64, i64, vp],
     "vita_cast_f32_bf16": [vp, i64, vp, i64, i64, i64, vp],
     "vita_colsum": [vp, i32, i64, i64, i64, vp, vp],
+    "vita_colsum_acc": [vp, i32, i64, i64, i64, vp, vp],
     "vita_softmax_rows": [vp, i64, vp, i64, i64, i64, f32, vp],
     "vita_softmax_bwd_rows": [vp, i64, vp, i64, vp, i64, i64, i64, f32, vp],
     "vita_l2_normalize_fwd": [vp, i64, i64, f32, vp, vp, vp],

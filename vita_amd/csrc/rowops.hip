@@ -529,12 +529,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
     if (col < cols) atomicAdd(out + col, red[0][sidx] + red[1][sidx] + red[2][sidx] + red[3][sidx]);
   }
 }
+static int colsum_impl(const void* x, int32_t dtype, int64_t ld, int64_t rows, int64_t cols, float* out, bool zero, void* stream);
 extern "C" int vita_colsum(const void* x, int32_t dtype, int64_t ld, int64_t rows, int64_t cols, float* out, void* stream) {
+  return colsum_impl(x, dtype, ld, rows, cols, out, true, stream);
+}
+extern "C" int vita_colsum_acc(const void* x, int32_t dtype, int64_t ld, int64_t rows, int64_t cols, float* out, void* stream) {
+  return colsum_impl(x, dtype, ld, rows, cols, out, false, stream);
+}
+static int colsum_impl(const void* x, int32_t dtype, int64_t ld, int64_t rows, int64_t cols, float* out, bool zero, void* stream) {
   const bool f32 = dtype == VITA_DT_F32;
   const int cpt = f32 ? 4 : 8;
   VITA_REQUIRE(x && out && rows > 0 && cols > 0 && ld % cpt == 0 && ld >= ((cols + cpt - 1) / cpt) * cpt);
   VITA_REQUIRE(((uintptr_t)x & 15) == 0);
-  if (hipMemsetAsync(out, 0, cols * sizeof(float), (hipStream_t)stream) != hipSuccess) return VITA_ERR_LAUNCH;
+  if (zero && hipMemsetAsync(out, 0, cols * sizeof(float), (hipStream_t)stream) != hipSuccess) return VITA_ERR_LAUNCH;
   const int64_t colblk = (cols + 64 * cpt - 1) / (64 * cpt);
   // about 2048 blocks in all, at least 64 rows per block, at most 256 row chunks: every chunk ends in one fp32 atomic
   // per column, and a narrow matrix (few column blocks) otherwise spends its time serialising them

@@ -12,6 +12,7 @@ Data layout in HBM:
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -166,15 +167,54 @@ def _wgrad_plan(m, n, k):
     return best[1], best[2]
 
 
-def wgrad(dy, lddy, x, ldx, rows_out, cols_out, k_tokens, row_seg=(0, 0), col_seg=(0, 0), m_phys=None, n_phys=None):
-    """dW[logical rows_out, cols_out] fp32 = dy^T x over k_tokens rows (both operands k-strided)."""
+INPLACE_PARAM_GRADS = os.environ.get("VITA_INPLACE_GRADS", "1") != "0"   # accumulate weight / bias gradients straight into an existing fp32 .grad (FlatAdam's flat buffer)
+GRAD_READY = {}              # id(param) -> callable(param): what a post-accumulate-grad hook would have been told
+
+
+def grad_target(param):
+    """The tensor a parameter gradient may be accumulated into directly (fp32 atomics of the split-K GEMM / colsum),
+    instead of materialising it and letting autograd run `grad += it`; None when there is no such buffer."""
+    g = param.grad if (INPLACE_PARAM_GRADS and param is not None) else None
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != param.shape or not g.is_cuda:
+        return None
+    return g
+
+
+def grad_done(param):
+    """After an in-place accumulation: run the hook autograd would have run (bucketed all-reduce bookkeeping)."""
+    hook = GRAD_READY.get(id(param))
+    if hook is not None:
+        hook(param)
+
+
+def wgrad(dy, lddy, x, ldx, rows_out, cols_out, k_tokens, row_seg=(0, 0), col_seg=(0, 0), m_phys=None, n_phys=None, param=None):
+    """dW[logical rows_out, cols_out] fp32 = dy^T x over k_tokens rows (both operands k-strided).
+    With `param` whose .grad is a usable fp32 buffer the product is ADDED to it (split-K atomics) and None is returned."""
     m = m_phys if m_phys is not None else rows_out
     n = n_phys if n_phys is not None else cols_out
     variant, sk = _wgrad_plan(m, n, k_tokens)
-    out = (torch.zeros if sk > 1 else torch.empty)(rows_out, cols_out, dtype=torch.float32, device=dy.device)
+    tgt = grad_target(param)
+    if tgt is not None:
+        sk = max(sk, 2)          # the atomic (accumulating) epilogue
+        out = tgt.view(rows_out, cols_out)
+    else:
+        out = (torch.zeros if sk > 1 else torch.empty)(rows_out, cols_out, dtype=torch.float32, device=dy.device)
     ops.gemm(dy, x, out, m, n, k_tokens, lddy, ldx, cols_out, a_layout=1, b_layout=1, split_k=sk, variant=variant,
              row_seg=row_seg, col_seg=col_seg, flops=2.0 * rows_out * cols_out * k_tokens)
+    if tgt is not None:
+        grad_done(param)
+        return None
     return out
+
+
+def bgrad(dy, ld, rows, cols, param=None):
+    """Bias gradient = column sums of dy; accumulated into param.grad when possible (returns None then)."""
+    tgt = grad_target(param)
+    if tgt is not None:
+        ops.colsum(dy, ld, rows, cols, out=tgt, accumulate=True)
+        grad_done(param)
+        return None
+    return ops.colsum(dy, ld, rows, cols)
 
 
 # ----------------------------------------------------------------------------- Block
@@ -218,25 +258,26 @@ class _BlockFn(torch.autograd.Function):
         dx2 = dx2.contiguous().view(M, Dp)
         dyb = ops.cast_bf16(dx2, Dp, M, D, Dp)
         # ---- MLP
-        d_fc2w = wgrad(dyb, Dp, g, dm.Hp, D, dm.hidden, M)
-        d_fc2b = ops.colsum(dyb, Dp, M, D)
+        a, mlp = blk.attn, blk.mlp
+        d_fc2w = wgrad(dyb, Dp, g, dm.Hp, D, dm.hidden, M, param=mlp.fc2.weight)
+        d_fc2b = bgrad(dyb, Dp, M, D, param=mlp.fc2.bias)
         du = torch.empty(M, dm.Hp, dtype=torch.bfloat16, device=x.device)   # GELU'(pre-activation), saved for backward
         ops.gemm(dyb, sh["fc2_w"], du, M, dm.Hp, Dp, Dp, dm.Hp, dm.Hp, b_layout=1, epilogue=ops.EPI_GELU_BWD, aux_in=u,
                  ld_aux=dm.Hp, flops=2.0 * M * D * dm.hidden)
-        d_fc1w = wgrad(du, dm.Hp, ln2, Dp, dm.hidden, D, M)
-        d_fc1b = ops.colsum(du, dm.Hp, M, dm.hidden)
+        d_fc1w = wgrad(du, dm.Hp, ln2, Dp, dm.hidden, D, M, param=mlp.fc1.weight)
+        d_fc1b = bgrad(du, dm.Hp, M, dm.hidden, param=mlp.fc1.bias)
         dln2 = torch.empty(M, Dp, dtype=torch.bfloat16, device=x.device)
         ops.gemm(du, sh["fc1_w"], dln2, M, Dp, dm.Hp, dm.Hp, Dp, Dp, b_layout=1, flops=2.0 * M * D * dm.hidden)
         del du
         dx1, dx1b, d_n2w, d_n2b = ops.layernorm_bwd(dln2, Dp, x1, Dp, n2w, mean2, rstd2, M, D, Dp, dx_in=dx2,
                                                     want_bf16=True, ld_dxb=Dp)
         # ---- attention
-        d_projw = wgrad(dx1b, Dp, o, dm.AO, D, D, M, col_seg=(dm.hdp, dm.hd), n_phys=dm.AO)
-        d_projb = ops.colsum(dx1b, Dp, M, D)
+        d_projw = wgrad(dx1b, Dp, o, dm.AO, D, D, M, col_seg=(dm.hdp, dm.hd), n_phys=dm.AO, param=a.proj.weight)
+        d_projb = bgrad(dx1b, Dp, M, D, param=a.proj.bias)
         do = torch.empty(M, dm.AO, dtype=torch.bfloat16, device=x.device)
         ops.gemm(dx1b, sh["proj_w"], do, M, dm.AO, Dp, Dp, dm.AO, dm.AO, b_layout=1, flops=2.0 * M * D * D)
         dqkv = attention_bwd(do, qkv, o, ctx.att_saved, B, N, dm)
-        d_qkvw = wgrad(dqkv, dm.QKV, ln1, Dp, 3 * D, D, M, row_seg=(dm.hdp, dm.hd), m_phys=dm.QKV)
+        d_qkvw = wgrad(dqkv, dm.QKV, ln1, Dp, 3 * D, D, M, row_seg=(dm.hdp, dm.hd), m_phys=dm.QKV, param=a.qkv.weight)
         d_qkvb = None
         if blk.attn.qkv.bias is not None:
             d_qkvb = ops.unpack_vec(ops.colsum(dqkv, dm.QKV, M, dm.QKV), 3 * D, seg=(dm.hdp, dm.hd))
@@ -344,6 +385,7 @@ class _LinearFn(torch.autograd.Function):
         y = torch.empty(M, Np, dtype=torch.float32, device=xp.device)
         ops.gemm(xb, ws, y, M, Np, Kp, Kp, Kp, Np, bias=bs, flops=2.0 * M * out_f * in_f)
         ctx.save_for_backward(xb, ws)
+        ctx.lin_w, ctx.lin_b = w, b
         ctx.dims = (B, N, Kp, Np, out_f, in_f)
         return y.view(B, N, Np)
 
@@ -354,8 +396,8 @@ class _LinearFn(torch.autograd.Function):
         M = B * N
         dy = dy.contiguous().view(M, Np)
         dyb = ops.cast_bf16(dy, Np, M, out_f, Np)
-        dw = wgrad(dyb, Np, xb, Kp, out_f, in_f, M)
-        db = ops.colsum(dyb, Np, M, out_f)
+        dw = wgrad(dyb, Np, xb, Kp, out_f, in_f, M, param=ctx.lin_w)
+        db = bgrad(dyb, Np, M, out_f, param=ctx.lin_b)
         dx = torch.empty(M, Kp, dtype=torch.float32, device=dy.device)
         ops.gemm(dyb, ws, dx, M, Kp, Np, Np, Kp, Kp, b_layout=1, flops=2.0 * M * out_f * in_f)
         return dx.view(B, N, Kp), dw, db, None, None

@@ -189,9 +189,12 @@ def cast_bf16(x, ldx, rows, d, ldy):
     return y
 
 
-def colsum(x, ld, rows, cols):
-    out = torch.empty(cols, dtype=torch.float32, device=x.device)
-    check(_lib.lib().vita_colsum(x.data_ptr(), _dt(x), ld, rows, cols, out.data_ptr(), _s()), "colsum")
+def colsum(x, ld, rows, cols, out=None, accumulate=False):
+    """Column sums; accumulate=True adds them to `out` (fp32 [cols]) instead of overwriting it."""
+    if out is None:
+        out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    fn = _lib.lib().vita_colsum_acc if accumulate else _lib.lib().vita_colsum
+    check(fn(x.data_ptr(), _dt(x), ld, rows, cols, out.data_ptr(), _s()), "colsum")
     return out
 
 

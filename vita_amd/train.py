@@ -135,8 +135,11 @@ class BucketedAllReduce:
         self.pending = [0] * len(self.buckets)
         self.handles = []
         self.launch_order = []
+        from . import nn as vnn
         for i, p in enumerate(opt.params):
-            p.register_post_accumulate_grad_hook(self._make_hook(i))
+            hook = self._make_hook(i)
+            p.register_post_accumulate_grad_hook(hook)
+            vnn.GRAD_READY[id(p)] = hook          # gradients accumulated in place by the kernels (no autograd accumulate)
 
     def _make_hook(self, i):
         def hook(_p):
