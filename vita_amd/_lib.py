@@ -57,14 +57,15 @@ SIGNATURES = {
     "vita_ce_rows": [vp, i64, i64, i64, i64, f32, vp, vp, vp, i64, vp],
     "vita_sigmoid_mse_patch": [vp, i64, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, f32, vp, vp, vp, i64, vp],
     "vita_attn_supported": [i64, i64],
-    "vita_attn_fwd": [vp, vp, vp, i64, i64, i64, i64, i64, f32, vp],
+    "vita_attn_fwd_ws_bytes": [i64],
+    "vita_attn_fwd": [vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, f32, vp],
     "vita_attn_bwd_ws_bytes": [i64, i64, i64, i64],
     "vita_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, f32, vp],
     "vita_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, i64, vp],
     "vita_cine_partial_floats": [i64],
     "vita_cine_prepare": [vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, i64, i32, vp, vp, vp, vp],
 }
-_I64_RET = {"vita_layernorm_bwd_nblk", "vita_cine_partial_floats", "vita_attn_bwd_ws_bytes"}
+_I64_RET = {"vita_layernorm_bwd_nblk", "vita_cine_partial_floats", "vita_attn_bwd_ws_bytes", "vita_attn_fwd_ws_bytes"}
 OPTIONAL = set()
 
 _lib = None

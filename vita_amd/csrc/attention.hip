@@ -243,15 +243,21 @@ __device__ __forceinline__ void lds_zero(char* smem, int bytes, int tid) {
 // ============================================================================================ forward
 template <int HDP, int NKS, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ o,
-                                                              float* __restrict__ lse, int N, int H, float c_exp2) {
+                                                              float* __restrict__ lse, float* __restrict__ part, int wg_base,
+                                                              int nsplit, int tiles_per_split, int N, int H, float c_exp2) {
   using C = AttCfg<HDP>;
   constexpr int RS = C::RS, NDT = C::NDT, BUF = 2 * C::TILE, NSLOT = ATT_NSLOT;
   constexpr int DPT = 2 * (32 / C::RPI / NW);                   // DMA instructions per wave per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];   // ring of NSLOT x [K image | V image]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = blockIdx.y, b = blockIdx.z;
+  // 1-D grid over (batch, head, NW*32-query block) x nsplit key ranges.  nsplit > 1 only in the tail launch (the last,
+  // partly filled round of workgroups): a workgroup then sweeps key tiles [t0, t1) and leaves its normalised fp32
+  // partial output and log2-sum-exp in `part`; attn_fwd_tail_combine_kernel merges the ranges.
+  const int QB = (N + NW * 32 - 1) / (NW * 32);
+  const int lin = wg_base + (int)blockIdx.x / nsplit, sp = (int)blockIdx.x % nsplit;
+  const int bx = lin % QB, h = (lin / QB) % H, b = lin / (QB * H);
   const int64_t ld = 3ll * H * HDP;
-  const int q0 = blockIdx.x * (NW * 32) + wave * 32;
+  const int q0 = bx * (NW * 32) + wave * 32;
   const uint16_t* base = qkv + (int64_t)b * N * ld;
   const uint32_t extent = (uint32_t)((((int64_t)N - 1) * ld + HDP) * 2);
   const __amdgpu_buffer_rsrc_t rsQ = mk_rsrc(base + h * HDP, extent);
@@ -274,6 +280,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const uint16_t* __
   float m_run = -INFINITY, l_run = 0.f;
 
   const int ntiles = (N + 31) / 32;
+  const int t0 = sp * tiles_per_split;
+  const int t1 = t0 + tiles_per_split < ntiles ? t0 + tiles_per_split : ntiles;
   LdsAddr<HDP, NKS> la;
   la.init(lane);
   constexpr int NI = 32 / C::RPI / NW;      // DMA pieces per wave per image
@@ -281,7 +289,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const uint16_t* __
   off.init(ld, wave, lane);
   // piece p of a tile's prefetch: [0,NI) K image, [NI,2NI) V image; tiles past the end read zeros
   auto issue_piece = [&](int tile, int buf, int p) {
-    const int tcl = tile < ntiles ? tile : ntiles;
+    const int tcl = tile < t1 ? tile : ntiles;
     const uint32_t toff = (uint32_t)tcl * (uint32_t)(32 * ld * 2);
     if (p < NI) off.issue(rsK, toff, smem + buf * BUF, wave, p);
     else off.issue(rsV, toff, smem + buf * BUF + C::TILE, wave, p - NI);
@@ -291,11 +299,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const uint16_t* __
     for (int p = 0; p < 2 * NI; ++p) issue_piece(tile, buf, p);
   };
   __syncthreads();
-  issue(0, 0); issue(1, 1);
-  dma_wait_n<DPT>();               // tile 0 has landed
+  issue(t0, 0); issue(t0 + 1, 1);
+  dma_wait_n<DPT>();               // tile t0 has landed
   ring_barrier();
   int slot = 0;
-  for (int kt = 0; kt < ntiles; ++kt) {
+  for (int kt = t0; kt < t1; ++kt) {
     const int pre = slot >= 1 ? slot - 1 : NSLOT - 1;     // slot of tile kt+2 = slot of tile kt-1
     const int kbase = kt * 32;
     if (active) {
@@ -365,7 +373,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const uint16_t* __
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l_tot;
   const int q = q0 + lq;
-  if (q < N) {
+  if (part != nullptr) {
+    // part[(tail workgroup * nsplit + split)]: [NW*32 queries][HDP] fp32 normalised output, then [NW*32] log2-sum-exp
+    float* pw_ = part + ((int64_t)(lin - wg_base) * nsplit + sp) * ((NW * 32) * (HDP + 1));
+    if (active) {
+      float* prow = pw_ + (int64_t)(wave * 32 + lq) * HDP;
+#pragma unroll
+      for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          *reinterpret_cast<f32x4*>(prow + i * 32 + 8 * rr + 4 * hh) =
+              f32x4{oacc[i][4 * rr] * inv, oacc[i][4 * rr + 1] * inv, oacc[i][4 * rr + 2] * inv, oacc[i][4 * rr + 3] * inv};
+      if (hh == 0) pw_[(NW * 32) * HDP + wave * 32 + lq] = m_run * c_exp2 + log2f(l_tot);
+    }
+  } else if (q < N) {
     uint16_t* orow = o + ((int64_t)b * N + q) * ((int64_t)H * HDP) + h * HDP;
 #pragma unroll
     for (int i = 0; i < NDT; ++i)
@@ -377,6 +398,35 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const uint16_t* __
       }
     if (hh == 0) lse[((int64_t)b * H + h) * N + q] = (m_run * c_exp2 + log2f(l_tot)) * 0.6931471805599453f;
   }
+}
+
+// merge the key ranges of the tail workgroups: o = sum_s o_s 2^(l_s - L), L = log2 sum_s 2^l_s (fixed order)
+__global__ __launch_bounds__(256) void attn_fwd_tail_combine_kernel(const float* __restrict__ part, uint16_t* __restrict__ o,
+                                                                    float* __restrict__ lse, int wg_base, int nwg, int nsplit,
+                                                                    int N, int H, int HDP, int QBS) {
+  const int c4 = HDP / 4;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)nwg * QBS * c4) return;
+  const int c = (int)(idx % c4), ql = (int)((idx / c4) % QBS), w = (int)(idx / ((int64_t)c4 * QBS));
+  const int QB = (N + QBS - 1) / QBS, lin = wg_base + w;
+  const int bx = lin % QB, h = (lin / QB) % H, b = lin / (QB * H);
+  const int q = bx * QBS + ql;
+  if (q >= N) return;
+  const int64_t stride = (int64_t)QBS * (HDP + 1);
+  const float* p0 = part + (int64_t)w * nsplit * stride;
+  float mx = -INFINITY;
+  for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, p0[s * stride + (int64_t)QBS * HDP + ql]);
+  float den = 0.f;
+  f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < nsplit; ++s) {
+    const float wgt = __builtin_amdgcn_exp2f(p0[s * stride + (int64_t)QBS * HDP + ql] - mx);
+    den += wgt;
+    a += *reinterpret_cast<const f32x4*>(p0 + s * stride + (int64_t)ql * HDP + c * 4) * wgt;
+  }
+  const float inv = 1.f / den;
+  uint16_t* orow = o + ((int64_t)b * N + q) * ((int64_t)H * HDP) + h * HDP + c * 4;
+  *reinterpret_cast<u32x2*>(orow) = u32x2{pack_bf16x2(a[0] * inv, a[1] * inv), pack_bf16x2(a[2] * inv, a[3] * inv)};
+  if (c == 0) lse[((int64_t)b * H + h) * N + q] = (mx + log2f(den)) * 0.6931471805599453f;
 }
 
 // ============================================================================================ backward
@@ -1110,10 +1160,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_ds_kernel(const uint16_t* 
                                                                        int, int, int, float);                        \
   template __global__ void attn_bwd_dq_kernel<A, K>(const uint16_t*, const uint16_t*, const float*, const float*,    \
                                                     uint16_t*, int, int, float);
-template __global__ void attn_fwd_kernel<224, 13, 8>(const uint16_t*, uint16_t*, float*, int, int, float);
-template __global__ void attn_fwd_kernel<64, 3, 8>(const uint16_t*, uint16_t*, float*, int, int, float);
-template __global__ void attn_fwd_kernel<32, 2, 8>(const uint16_t*, uint16_t*, float*, int, int, float);
-template __global__ void attn_fwd_kernel<128, 8, 8>(const uint16_t*, uint16_t*, float*, int, int, float);
+template __global__ void attn_fwd_kernel<224, 13, 8>(const uint16_t*, uint16_t*, float*, float*, int, int, int, int, int, float);
+template __global__ void attn_fwd_kernel<64, 3, 8>(const uint16_t*, uint16_t*, float*, float*, int, int, int, int, int, float);
+template __global__ void attn_fwd_kernel<32, 2, 8>(const uint16_t*, uint16_t*, float*, float*, int, int, int, int, int, float);
+template __global__ void attn_fwd_kernel<128, 8, 8>(const uint16_t*, uint16_t*, float*, float*, int, int, int, int, int, float);
 ATT_INSTANTIATE_BWD(224, 13)
 ATT_INSTANTIATE_BWD(64, 3)
 ATT_INSTANTIATE_BWD(32, 2)
@@ -1121,25 +1171,7 @@ ATT_INSTANTIATE_BWD(128, 8)
 #undef ATT_INSTANTIATE_BWD
 
 // ============================================================================================ host
-template <int HDP, int NKS>
-static int launch_fwd(const void* qkv, void* o, float* lse, int64_t B, int64_t N, int64_t H, float scale, hipStream_t s) {
-  constexpr int NW = 8;
-  const size_t lds = ATT_NSLOT * 2 * AttCfg<HDP>::TILE;
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HDP, NKS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  dim3 grid((unsigned)((N + NW * 32 - 1) / (NW * 32)), (unsigned)H, (unsigned)B);
-  hipLaunchKernelGGL((attn_fwd_kernel<HDP, NKS, NW>), grid, dim3(NW * 64), lds, s, (const uint16_t*)qkv, (uint16_t*)o, lse, (int)N, (int)H,
-                     scale * 1.4426950408889634f);
-  VITA_CHECK_LAUNCH("vita_attn_fwd");
-  return VITA_OK;
-}
-
-// dS hand-off geometry: query tiles QT = ceil(N/32), key blocks padded to the dK/dV grid KTP = 4 * ceil(N/128)
-static inline int64_t att_qt(int64_t N) { return (N + 31) / 32; }
-static inline int64_t att_ktp(int64_t N) { return 4 * ((N + 127) / 128); }
-// workspace = [ fp32 partial dK/dV of the tail workgroups (fixed upper bound) | bf16 dS tiles ]
 #define ATT_MAX_CU 320
-static inline int64_t att_part_bytes(int64_t hdp) { return (int64_t)ATT_MAX_CU * 2 * 128 * hdp * 4; }
 static int att_num_cu() {
   static int n = 0;
   if (n == 0) {
@@ -1150,9 +1182,9 @@ static int att_num_cu() {
   }
   return n;
 }
-// The dK/dV grid runs one 8-wave workgroup per CU, every workgroup takes the same time, so a grid of L workgroups
-// costs ceil(L / CUs) rounds.  When the last round is less than 3/4 full its `rem` workgroups are launched
-// separately with their query sweep cut into nsplit ranges (rem * nsplit <= CUs, >= 8 tiles per range).
+// These grids run one 8-wave workgroup per CU and every workgroup of a launch does the same work, so a grid of L
+// workgroups costs ceil(L / CUs) rounds.  When the last round is less than 3/4 full its `rem` workgroups are launched
+// separately with their sweep cut into nsplit ranges (rem * nsplit <= CUs, >= 8 tiles per range).
 static void att_tail_plan(int64_t L, int64_t ntiles, int ncu, int64_t* l_main, int* nsplit, int* tiles_per_split) {
   *l_main = L; *nsplit = 1; *tiles_per_split = (int)ntiles;
   const int64_t rem = L % ncu;
@@ -1163,6 +1195,45 @@ static void att_tail_plan(int64_t L, int64_t ntiles, int ncu, int64_t* l_main, i
   const int64_t per = (ntiles + ns - 1) / ns;
   *l_main = L - rem; *nsplit = (int)((ntiles + per - 1) / per); *tiles_per_split = (int)per;
 }
+static inline int64_t att_fwd_part_bytes(int64_t hdp) { return (int64_t)ATT_MAX_CU * 256 * (hdp + 1) * 4; }
+
+template <int HDP, int NKS>
+static int launch_fwd(const void* qkv, void* o, float* lse, void* ws, int64_t B, int64_t N, int64_t H, float scale, hipStream_t s) {
+  constexpr int NW = 8;
+  const size_t lds = ATT_NSLOT * 2 * AttCfg<HDP>::TILE;
+  static bool attr = false;
+  static bool no_tail = false;    // VITA_ATTN_NO_TAIL_SPLIT=1: A/B switch of the tail launch
+  if (!attr) {
+    const char* e = getenv("VITA_ATTN_NO_TAIL_SPLIT");
+    no_tail = e && e[0] == '1';
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HDP, NKS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = true;
+  }
+  const int64_t L = B * H * ((N + NW * 32 - 1) / (NW * 32));
+  const int ntiles = (int)((N + 31) / 32);
+  int64_t l_main = L; int nsplit = 1, per = ntiles;
+  if (ws != nullptr && !no_tail) att_tail_plan(L, ntiles, att_num_cu(), &l_main, &nsplit, &per);
+  const float c = scale * 1.4426950408889634f;
+  if (l_main > 0)
+    hipLaunchKernelGGL((attn_fwd_kernel<HDP, NKS, NW>), dim3((unsigned)l_main), dim3(NW * 64), lds, s, (const uint16_t*)qkv, (uint16_t*)o,
+                       lse, (float*)nullptr, 0, 1, ntiles, (int)N, (int)H, c);
+  if (l_main < L) {
+    const int nwg = (int)(L - l_main);
+    hipLaunchKernelGGL((attn_fwd_kernel<HDP, NKS, NW>), dim3((unsigned)(nwg * nsplit)), dim3(NW * 64), lds, s, (const uint16_t*)qkv,
+                       (uint16_t*)o, lse, (float*)ws, (int)l_main, nsplit, per, (int)N, (int)H, c);
+    const int64_t nthr = (int64_t)nwg * (NW * 32) * (HDP / 4);
+    hipLaunchKernelGGL(attn_fwd_tail_combine_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (const float*)ws,
+                       (uint16_t*)o, lse, (int)l_main, nwg, nsplit, (int)N, (int)H, HDP, NW * 32);
+  }
+  VITA_CHECK_LAUNCH("vita_attn_fwd");
+  return VITA_OK;
+}
+
+// dS hand-off geometry: query tiles QT = ceil(N/32), key blocks padded to the dK/dV grid KTP = 4 * ceil(N/128)
+static inline int64_t att_qt(int64_t N) { return (N + 31) / 32; }
+static inline int64_t att_ktp(int64_t N) { return 4 * ((N + 127) / 128); }
+// workspace = [ fp32 partial dK/dV of the tail workgroups (fixed upper bound) | bf16 dS tiles ]
+static inline int64_t att_part_bytes(int64_t hdp) { return (int64_t)ATT_MAX_CU * 2 * 128 * hdp * 4; }
 
 template <int HDP, int NKS>
 static int launch_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, void* ws,
@@ -1236,14 +1307,17 @@ extern "C" int vita_attn_supported(int64_t hd, int64_t hdp) {
   return (hdp == 224 && nks == 13) || (hdp == 64 && nks == 3) || (hdp == 32 && nks == 2) || (hdp == 128 && nks == 8);
 }
 
-extern "C" int vita_attn_fwd(const void* qkv, void* o, float* lse, int64_t B, int64_t N, int64_t H, int64_t hd, int64_t hdp,
-                             float scale, void* stream) {
+extern "C" int64_t vita_attn_fwd_ws_bytes(int64_t hdp) { return hdp > 0 ? att_fwd_part_bytes(hdp) : 0; }
+
+extern "C" int vita_attn_fwd(const void* qkv, void* o, float* lse, void* ws, int64_t ws_bytes, int64_t B, int64_t N, int64_t H,
+                             int64_t hd, int64_t hdp, float scale, void* stream) {
   VITA_REQUIRE(qkv && o && lse && B > 0 && N > 0 && H > 0 && B < 65536 && H < 65536);
-  VITA_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 7) == 0);
+  VITA_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)o & 7) == 0 && ((uintptr_t)ws & 15) == 0);
+  VITA_REQUIRE(ws == nullptr || ws_bytes >= vita_attn_fwd_ws_bytes(hdp));
   VITA_REQUIRE((N + 64) * 3 * H * hdp * 2 < (int64_t)0xffffffffll);
   hipStream_t s = (hipStream_t)stream;
   const int64_t nks = (hd + 15) / 16;
-#define FWD_CALL(A, K) launch_fwd<A, K>(qkv, o, lse, B, N, H, scale, s)
+#define FWD_CALL(A, K) launch_fwd<A, K>(qkv, o, lse, ws, B, N, H, scale, s)
   ATT_DISPATCH(FWD_CALL)
 #undef FWD_CALL
   vita_set_error("vita_attn_fwd: unsupported head dim", hipSuccess);

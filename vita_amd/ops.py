@@ -247,9 +247,14 @@ def attn_supported(hd, hdp):
     return bool(_lib.lib().vita_attn_supported(hd, hdp))
 
 
-def attn_fwd(qkv, o, lse, B, N, H, hd, hdp, scale):
+def attn_fwd(qkv, o, lse, B, N, H, hd, hdp, scale, tail_split=True):
+    ws, ws_bytes = None, 0
+    if tail_split:          # scratch for the split tail launch (fixed size, reused by the caching allocator)
+        ws_bytes = _lib.lib().vita_attn_fwd_ws_bytes(hdp)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device)
     with _Timed("attn_fwd_kernel", 4.0 * B * H * N * N * hd):
-        check(_lib.lib().vita_attn_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), B, N, H, hd, hdp, scale, _s()), "attn_fwd")
+        check(_lib.lib().vita_attn_fwd(qkv.data_ptr(), o.data_ptr(), lse.data_ptr(), _p(ws), ws_bytes, B, N, H, hd, hdp, scale,
+                                       _s()), "attn_fwd")
 
 
 ATTN_DS_HANDOFF = True      # dS tiles through HBM scratch (B*H*N^2*2 B): dQ without the S / dP recompute
