@@ -462,3 +462,32 @@ def test_cine_prepare_batch_full_size(ops):
         prepare_cine_batch(dev(torch.from_numpy(lax)), dev(torch.from_numpy(sax)), z0=8, sax_slice_num=6)
     with pytest.raises(RuntimeError):
         prepare_cine_batch(torch.from_numpy(lax), torch.from_numpy(sax))
+
+
+@pytest.mark.parametrize("lb", [0, 1])
+def test_gemm_large_m_epilogues(ops, lb):
+    """M beyond one round of 256-row tiles (43 x 6 tiles, ragged last row panel) through the shape-chosen kernel with
+    every epilogue (residual / saved GELU derivative / GELU-backward factor)."""
+    torch.manual_seed(7 + lb)
+    m, n, k = 10752 + 200, 1088, 136
+    A = bf(torch.randn(m, k)); W = bf(torch.randn(n, k) * 0.1); bias = torch.randn(n)
+    wt = dev(W) if lb == 0 else dev(W.t().contiguous())
+    ldb = k if lb == 0 else n
+    pre_nb = A.float() @ W.float().t()
+    pre = pre_nb + bias
+    kw = dict(b_layout=lb)
+    c0 = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ops.gemm(dev(A), wt, c0, m, n, k, k, ldb, n, **kw)
+    torch.testing.assert_close(c0.cpu().float(), pre_nb, rtol=2e-2, atol=2e-2)
+    c = torch.empty(m, n, dtype=torch.bfloat16, device="cuda"); u = torch.full((m, n), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ops.gemm(dev(A), wt, c, m, n, k, k, ldb, n, bias=dev(bias), epilogue=ops.EPI_GELU, aux_out=u, **kw)
+    torch.testing.assert_close(u.cpu().float(), _gelu_grad(pre), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(c.cpu().float(), torch.nn.functional.gelu(pre), rtol=2e-2, atol=2e-2)
+    res = torch.randn(m, n)
+    c2 = torch.full((m, n), float("nan"), device="cuda")
+    ops.gemm(dev(A), wt, c2, m, n, k, k, ldb, n, bias=dev(bias), epilogue=ops.EPI_RESIDUAL, aux_in=dev(res), ld_aux=n, **kw)
+    torch.testing.assert_close(c2.cpu(), pre + res, rtol=1e-3, atol=2e-3)
+    uu = bf(_gelu_grad(torch.randn(m, n)))
+    c3 = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+    ops.gemm(dev(A), wt, c3, m, n, k, k, ldb, n, epilogue=ops.EPI_GELU_BWD, aux_in=dev(uu), ld_aux=n, **kw)
+    torch.testing.assert_close(c3.cpu().float(), pre_nb * uu.float(), rtol=2e-2, atol=2e-2)

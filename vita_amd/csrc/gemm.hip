@@ -293,7 +293,9 @@ extern "C" int vita_gemm_bf16_ex(const vita_gemm_desc* dp, int32_t variant, void
     // large un-batched problems: whichever kernel needs fewer (weighted) rounds of workgroups
     if (ok && d.m >= 512 && d.n >= 208 && d.k >= 256) {
       int nf = 0;
-      if (vita_gemm256_cost(d, &nf) <= vita_gemm128_cost(d)) return vita_gemm256_launch(d, nf, (hipStream_t)stream);
+      if (vita_gemm256_cost(d, &nf) <= vita_gemm128_cost(d)) {
+        return vita_gemm256_launch(d, nf, (hipStream_t)stream);
+      }
     }
   }
   GemmParams P;

@@ -14,6 +14,7 @@
 //     k-strided operand   : LDS image [64 k][512 B], 32-B chunk ^ f(k), ds_read_b64_tr_b16
 //   * grouped XCD-aware raster: the 32 tiles running on one XCD form 8 M-panels x 4 N-panels
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 #define G2_BM 256
@@ -455,13 +456,13 @@ double vita_gemm256_cost(const vita_gemm_desc& d, int* nf_out) {
   if (nf_out) *nf_out = best_nf;
   return best;
 }
-// the 128x128 kernel (2 workgroups per CU) in the same units: a round of 512 tiles costs 15-19 units on the model's
-// shapes (M = 13826: proj 18.7, fc2 19, dln2 16.4, dln1 15.2, do 16 - measured against the 256-row kernel's rounds)
+// the 128x128 kernel in the same units: a CU works through ceil(tiles / 256) of them, one costing about 8.75 units
+// (two co-resident tiles share a CU: a full round of 512 costs 15-19 units on the model's shapes - M = 13826: proj
+// 18.7, fc2 19, dln2 16.4, dln1 15.2, do 16, measured against the 256-row kernel's rounds)
 double vita_gemm128_cost(const vita_gemm_desc& d) {
   const int64_t t = ((d.m + 127) / 128) * ((d.n + 127) / 128) * d.split_k;
-  return (double)((t + 511) / 512) * 17.5 / d.split_k;
+  return (double)((t + 255) / 256) * 8.75 / d.split_k;
 }
-
 // Whether the large-tile kernel can run this descriptor (already validated / normalised by vita_gemm_bf16).
 bool vita_gemm256_supported(const vita_gemm_desc& d) {
   if (d.batch_outer * d.batch_inner != 1) return false;
