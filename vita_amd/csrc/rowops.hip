@@ -13,47 +13,79 @@ extern "C" int vita_version(void) { return 100; }
 
 // ------------------------------------------------------------------------------------- LayerNorm
 #define LN_MAXV 8   // float4 per lane -> d <= 2048
+// R rows per wave: every row's loads are in flight before the first reduction (more bytes in flight per wave
+// than one row gives; a one-row-per-wave version reads at 2.0-2.3 TB/s, two rows 2.6-2.7)
+#define LN_FWD_R 4
 template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int64_t ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      void* __restrict__ y, int64_t ldy, int y_f32,
                                                      float* __restrict__ mean, float* __restrict__ rstd,
                                                      int64_t rows, int d, float eps) {
+  constexpr int R = LN_FWD_R;
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const float* xr = x + row * ldx;
-  f32x4 v[NV];
-  float s = 0.f;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= rows) return;
+  f32x4 v[R][NV];
+  float s[R];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = (i * 64 + lane) * 4;
-    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (c < d) {
-      v[i] = *reinterpret_cast<const f32x4*>(xr + c);
+  for (int k = 0; k < R; ++k) {
+    const int64_t row = row0 + k < rows ? row0 + k : rows - 1;      // clamped: loads stay in bounds, stores are guarded
+    const float* xr = x + row * ldx;
+    s[k] = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { if (c + r >= d) v[i][r] = 0.f; s += v[i][r]; }
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      v[k][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (c < d) v[k][i] = *reinterpret_cast<const f32x4*>(xr + c);
     }
   }
-  const float mu = wave_sum(s) / (float)d;
-  float q = 0.f;
+  const float inv_d = 1.f / (float)d;
+  float mu[R], rs[R];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int c = (i * 64 + lane) * 4;
+  for (int k = 0; k < R; ++k) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) if (c + r < d) { const float t = v[i][r] - mu; q += t * t; }
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { if (c + r >= d) v[k][i][r] = 0.f; s[k] += v[k][i][r]; }
+    }
   }
-  const float rs = rsqrtf(wave_sum(q) / (float)d + eps);
-  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+  for (int k = 0; k < R; ++k) mu[k] = wave_sum(s[k]) * inv_d;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (c + r < d) { const float t = v[k][i][r] - mu[k]; q += t * t; }
+    }
+    s[k] = q;
+  }
+#pragma unroll
+  for (int k = 0; k < R; ++k) rs[k] = rsqrtf(wave_sum(s[k]) * inv_d + eps);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) if (row0 + k < rows) { mean[row0 + k] = mu[k]; rstd[row0 + k] = rs[k]; }
+  }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
     if (c >= ldy) continue;
-    float o[4];
+    float g[4], bt[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = (c + r < d) ? (v[i][r] - mu) * rs * gamma[c + r] + beta[c + r] : 0.f;
-    if (y_f32) *reinterpret_cast<f32x4*>((float*)y + row * ldy + c) = f32x4{o[0], o[1], o[2], o[3]};
-    else *reinterpret_cast<u32x2*>((uint16_t*)y + row * ldy + c) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+    for (int r = 0; r < 4; ++r) { g[r] = (c + r < d) ? gamma[c + r] : 0.f; bt[r] = (c + r < d) ? beta[c + r] : 0.f; }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      if (row0 + k >= rows) continue;
+      float o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (c + r < d) ? (v[k][i][r] - mu[k]) * rs[k] * g[r] + bt[r] : 0.f;
+      if (y_f32) *reinterpret_cast<f32x4*>((float*)y + (row0 + k) * ldy + c) = f32x4{o[0], o[1], o[2], o[3]};
+      else *reinterpret_cast<u32x2*>((uint16_t*)y + (row0 + k) * ldy + c) = u32x2{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+    }
   }
 }
 
@@ -66,7 +98,7 @@ extern "C" int vita_layernorm_fwd(const float* x, int64_t ldx, const float* gamm
   VITA_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0);
   const int64_t width = ldy > d ? ldy : d;
 #define LN_FWD_LAUNCH(NV)                                                                                                     \
-  hipLaunchKernelGGL(ln_fwd_kernel<NV>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, \
+  hipLaunchKernelGGL(ln_fwd_kernel<NV>, dim3((unsigned)((rows + 4 * LN_FWD_R - 1) / (4 * LN_FWD_R))), dim3(256), 0, (hipStream_t)stream, x, ldx, gamma, \
                      beta, y, ldy, y_dtype == VITA_DT_F32, mean, rstd, rows, (int)d, eps)
   if (width <= 512) LN_FWD_LAUNCH(2);
   else if (width <= 1280) LN_FWD_LAUNCH(5);
@@ -450,16 +482,27 @@ extern "C" int vita_tokens_assemble(const float* y, int64_t ldy, const float* cl
 }
 
 // ------------------------------------------------------------------------------------- cast / colsum
+// four independent 16-B loads in flight per thread (grid-stride over 4-column units)
 __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, int64_t ldx, uint16_t* __restrict__ y,
                                                    int64_t ldy, int64_t rows, int d) {
-  const int64_t units = ldy >> 2;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * units; i += (int64_t)gridDim.x * 256) {
-    const int64_t r = i / units; const int c = (int)(i % units) * 4;
-    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (c < d) { v = *reinterpret_cast<const f32x4*>(x + r * ldx + c);
+  const int64_t units = ldy >> 2, total = rows * units, stride = (int64_t)gridDim.x * 256;
+  for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += 4 * stride) {
+    f32x4 v[4];
+    int64_t r[4]; int c[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) if (c + k >= d) v[k] = 0.f; }
-    *reinterpret_cast<u32x2*>(y + r * ldy + c) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    for (int u = 0; u < 4; ++u) {
+      const int64_t i = i0 + u * stride;
+      r[u] = i / units; c[u] = (int)(i % units) * 4;
+      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < total && c[u] < d) v[u] = *reinterpret_cast<const f32x4*>(x + r[u] * ldx + c[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (i0 + u * stride >= total) continue;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (c[u] + k >= d) v[u][k] = 0.f;
+      *reinterpret_cast<u32x2*>(y + r[u] * ldy + c[u]) = u32x2{pack_bf16x2(v[u][0], v[u][1]), pack_bf16x2(v[u][2], v[u][3])};
+    }
   }
 }
 extern "C" int vita_cast_f32_bf16(const float* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int64_t d, void* stream) {
