@@ -30,11 +30,41 @@ def _run(fn, world=2):
     return [ret[r] for r in range(world)]
 
 
+class _InPlaceScale(torch.autograd.Function):
+    """y = x * w with dL/dw accumulated straight into w.grad and reported through vita_amd.nn.grad_done - what the HIP
+    weight-gradient path does on the GPU (autograd gets None back and, in torch 2.10, still runs the post-accumulate
+    hook: the parameter must be counted once, or its bucket is all-reduced twice)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x * w
+
+    @staticmethod
+    def backward(ctx, g):
+        from vita_amd import nn as vnn
+        x, w = ctx.saved_tensors
+        w.grad.add_((g * x).sum(0))
+        vnn.grad_done(w)
+        return g * w, None
+
+
+class _Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.seq = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.GELU(), torch.nn.Linear(300, 300), torch.nn.GELU(),
+                                       torch.nn.Linear(300, 7))
+        self.scale = torch.nn.Parameter(torch.linspace(0.5, 1.5, 7))
+
+    def forward(self, x, inplace):
+        y = self.seq(x)
+        return _InPlaceScale.apply(y, self.scale) if inplace else y * self.scale
+
+
 def _bucketed(rank, world):
     from vita_amd.train import BucketedAllReduce, FlatAdam
     torch.manual_seed(0)
-    net = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.GELU(), torch.nn.Linear(300, 300), torch.nn.GELU(),
-                              torch.nn.Linear(300, 7))
+    net = _Net()
     frozen = torch.nn.Parameter(torch.zeros(5), requires_grad=False)
     opt = FlatAdam(list(net.parameters()) + [frozen], lr=1e-3)
     red = BucketedAllReduce(opt, bucket_mb=0.2)     # ~52k floats per bucket -> several buckets
@@ -45,8 +75,7 @@ def _bucketed(rank, world):
     for step in range(2):
         opt.zero_grad()
         x = torch.randn(16, 40, generator=torch.Generator().manual_seed(100 + 10 * step + rank))
-        net(x).square().mean().backward()
-        local = opt.g.clone() if False else None
+        net(x, True).square().mean().backward()
         red.finish()
         # every bucket launched exactly once, last-registered parameters first (backward order)
         assert sorted(red.launch_order[-len(red.buckets):]) == list(range(len(red.buckets)))
@@ -62,14 +91,13 @@ def test_bucketed_allreduce_equals_sum_of_rank_grads():
     assert order0 == order1 == sorted(order0)     # bucket 0 = tail of the parameter list = first ready
     # oracle: serial "fake world" - per-rank grads computed in one process and summed
     torch.manual_seed(0)
-    net = torch.nn.Sequential(torch.nn.Linear(40, 300), torch.nn.GELU(), torch.nn.Linear(300, 300), torch.nn.GELU(),
-                              torch.nn.Linear(300, 7))
+    net = _Net()
     for step in range(2):
         tot = None
         for rank in range(2):
             net.zero_grad()
             x = torch.randn(16, 40, generator=torch.Generator().manual_seed(100 + 10 * step + rank))
-            net(x).square().mean().backward()
+            net(x, False).square().mean().backward()
             flat = torch.cat([torch.nn.functional.pad(p.grad.flatten(), (0, (-p.numel()) % 4)) for p in net.parameters()])
             tot = flat if tot is None else tot + flat
         for g in (g0, g1):

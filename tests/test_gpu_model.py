@@ -314,3 +314,47 @@ def test_stage2_step_vs_oracle():
         assert torch.nn.functional.cosine_similarity(g.flatten(), gr.flatten(), dim=0) > 0.99, k
     loss2, _, _ = stage2_train_step(model, opt, imgs.cuda(), tabs.cuda())
     assert torch.isfinite(loss2)
+
+
+def test_stage1_step_with_rccl_reducer_world1():
+    """The data-parallel step driver on the GPU with a real RCCL process group of one rank: gradients accumulated in
+    place by the kernels (no autograd accumulate) must still tell BucketedAllReduce about every parameter exactly once,
+    every bucket must be all-reduced, and the result must equal the reducer-free step (all-reduce over one rank =
+    identity) - and the run with autograd's own accumulation (VITA_INPLACE_GRADS off)."""
+    import socket
+    import torch.distributed as dist
+    from vita_amd import nn as vnn
+    from vita_amd.train import BucketedAllReduce, FlatAdam, stage1_train_step
+    torch.manual_seed(3)
+    imgs = torch.rand(2, *IMG).cuda()
+
+    def run(reducer_on, inplace):
+        vnn.INPLACE_PARAM_GRADS = inplace
+        vnn.GRAD_READY.clear()
+        model, _ = build()
+        opt = FlatAdam(model.parameters(), lr=1e-4)
+        red = BucketedAllReduce(opt, bucket_mb=0.5) if reducer_on else None
+        draw_noise(77, 2, L_TOK)
+        loss = stage1_train_step(model, opt, imgs, red)
+        torch.cuda.synchronize()
+        if red is not None:
+            assert len(red.buckets) >= 2 and sorted(red.launch_order) == list(range(len(red.buckets))), \
+                (reducer_on, inplace, red.launch_order, [b[2] for b in red.buckets])
+            assert red.pending == [0] * len(red.buckets) and not red.handles
+        return loss.item(), opt.g.clone(), opt.p.clone()
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        base = run(False, True)
+        for reducer_on, inplace in ((True, True), (True, False), (False, False)):
+            got = run(reducer_on, inplace)
+            assert abs(got[0] - base[0]) <= 1e-6 * abs(base[0])
+            # split-K fp32 atomics: summation order differs run to run, values agree to rounding
+            torch.testing.assert_close(got[1], base[1], rtol=1e-3, atol=1e-7)
+            torch.testing.assert_close(got[2], base[2], rtol=0, atol=2.1e-4)      # Adam moves each weight by <= lr
+    finally:
+        vnn.INPLACE_PARAM_GRADS = True
+        vnn.GRAD_READY.clear()
+        dist.destroy_process_group()

@@ -133,6 +133,7 @@ class BucketedAllReduce:
             if hi - lo >= cap or i == 0:
                 self.buckets.append((lo, hi, cnt)); hi = lo; cnt = 0
         self.pending = [0] * len(self.buckets)
+        self.fired = {}             # parameter indices that reported since the last finish()
         self.handles = []
         self.launch_order = []
         from . import nn as vnn
@@ -143,7 +144,14 @@ class BucketedAllReduce:
 
     def _make_hook(self, i):
         def hook(_p):
+            # A parameter reports once per step.  Gradients accumulated in place by the kernels report through
+            # vita_amd.nn.GRAD_READY right after their launch; autograd (torch 2.10) then ALSO runs the post-accumulate
+            # hook for the None it got back - the second report must not launch the bucket again (a second all-reduce
+            # would multiply the gradient by the world size).  No parameter of these models is used twice in one graph.
+            if i in self.fired:
+                return
             b = self.bucket_of[i]
+            self.fired[i] = 1
             self.pending[b] += 1
             if self.pending[b] == self.buckets[b][2]:
                 self._launch(b)
@@ -170,6 +178,7 @@ class BucketedAllReduce:
             torch.cuda.current_stream().wait_stream(self.stream)
         self.handles = []
         self.pending = [0] * len(self.buckets)
+        self.fired = {}
 
 
 def warmup_cosine_lr(base_lr, step, num_warmup_steps, num_training_steps, num_cycles=0.5):
