@@ -231,6 +231,12 @@ __device__ __forceinline__ void ring_barrier() {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
+// Workgroup id -> work item so that the ids an XCD receives (id % 8, round-robin dispatch) form one contiguous range of
+// work items: the workgroups sharing an XCD's L2 then sweep the same head's K/V (resp. Q/dO) stream.
+__device__ __forceinline__ int xcd_contiguous(int id, int n) {
+  const int q = n >> 3, r = n & 7, xcd = id & 7, idx = id >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
 #define ATT_NSLOT 3
 #define ATT_BWD_NSLOT 4   // the software-pipelined dK/dV kernel keeps tiles t .. t+3 in the ring
 #define ATT_DQDS_NSLOT 4  // ring depth of the streaming dQ kernel (K image + 8 dS tiles = 32 KiB per slot at hdp 224)
@@ -254,7 +260,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const uint16_t* __
   // partly filled round of workgroups): a workgroup then sweeps key tiles [t0, t1) and leaves its normalised fp32
   // partial output and log2-sum-exp in `part`; attn_fwd_tail_combine_kernel merges the ranges.
   const int QB = (N + NW * 32 - 1) / (NW * 32);
-  const int lin = wg_base + (int)blockIdx.x / nsplit, sp = (int)blockIdx.x % nsplit;
+  const int lin = nsplit == 1 ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : wg_base + (int)blockIdx.x / nsplit;
+  const int sp = (int)blockIdx.x % nsplit;
   const int bx = lin % QB, h = (lin / QB) % H, b = lin / (QB * H);
   const int64_t ld = 3ll * H * HDP;
   const int q0 = bx * (NW * 32) + wave * 32;
@@ -671,7 +678,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
   // partly filled round of workgroups): each workgroup then sweeps tiles [t0, t1) of the queries and leaves fp32
   // partial dK / dV in `part`, summed in a fixed order by attn_bwd_tail_reduce_kernel.
   const int KB = (N + 127) >> 7;
-  const int lin = wg_base + (int)blockIdx.x / nsplit, sp = (int)blockIdx.x % nsplit;
+  const int lin = nsplit == 1 ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : wg_base + (int)blockIdx.x / nsplit;
+  const int sp = (int)blockIdx.x % nsplit;
   const int bx = lin % KB, h = (lin / KB) % H, b = lin / (KB * H);
   const int64_t ld = 3ll * H * HDP, ldo = (int64_t)H * HDP;
   const uint16_t* base = qkv + (int64_t)b * N * ld;
