@@ -239,7 +239,7 @@ __device__ __forceinline__ int xcd_contiguous(int id, int n) {
 }
 #define ATT_NSLOT 3
 #define ATT_BWD_NSLOT 4   // the software-pipelined dK/dV kernel keeps tiles t .. t+3 in the ring
-#define ATT_DQDS_NSLOT 4  // ring depth of the streaming dQ kernel (K image + 8 dS tiles = 32 KiB per slot at hdp 224)
+#define ATT_DQDS_NSLOT 5  // ring depth of the streaming dQ kernel (K image + 8 dS tiles = 32 KiB per slot at hdp 224: all 160 KiB)
 
 template <int HDP>
 __device__ __forceinline__ void lds_zero(char* smem, int bytes, int tid) {
@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_ds_kernel(const uint16_t* 
       const int j = p - NI;
       const uint32_t toff = (uint32_t)tile * (uint32_t)QT * 2048u + j * 1024;     // past KTP: beyond the descriptor, zeros
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsDS, (lds_void*)(bp + TILE + wave * 2048 + j * 1024), 16,
-                                               qt_ok ? ds_voff + toff : 0xfffffff0u, 0, 0, 0);
+                                               qt_ok ? ds_voff + toff : 0xfffffff0u, 0, 0, 2);
     }
   };
   auto issue = [&](int tile, int buf) {
