@@ -180,11 +180,65 @@ def grad_target(param):
     return g
 
 
+_DEFERRED_DONE = None         # list while a Block backward has launches in flight on its side stream
+
+
 def grad_done(param):
-    """After an in-place accumulation: run the hook autograd would have run (bucketed all-reduce bookkeeping)."""
+    """After an in-place accumulation: run the hook autograd would have run (bucketed all-reduce bookkeeping).
+    While a side stream holds the accumulating launches the report waits for the join (_SideStream.join)."""
+    if _DEFERRED_DONE is not None:
+        _DEFERRED_DONE.append(param)
+        return
     hook = GRAD_READY.get(id(param))
     if hook is not None:
         hook(param)
+
+
+WGRAD_SIDE_STREAM = os.environ.get("VITA_WGRAD_STREAM", "1") != "0"
+_SIDE_STREAMS = {}            # device index -> the second HIP stream of that device
+
+
+class _SideStream:
+    """Weight / bias gradient launches of one Block backward on a second HIP stream.
+
+    dW = dY^T X and colsum(dY) depend only on dY, never on the dgrad chain that follows, so they run beside it: the
+    256-row GEMM grids are 1-4 rounds of one workgroup per CU, and a second independent grid fills the CUs a
+    partial last round leaves idle and takes the workgroups of the two kernels out of lock-step (their epilogue
+    store bursts no longer coincide).  fork() orders the side stream after everything issued so far on the main
+    stream; join() makes the main stream wait for the side stream and only then reports the accumulated gradients
+    (the bucketed all-reduce orders its communication stream after the main stream).  Every tensor the side
+    stream touches stays referenced by the caller until join(), so the caching allocator cannot hand its memory
+    to a main-stream allocation while the side stream still uses it."""
+
+    def __init__(self, device, enabled=True):
+        self.on = bool(enabled and WGRAD_SIDE_STREAM)
+        if not self.on:
+            return
+        global _DEFERRED_DONE
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        self.side = _SIDE_STREAMS.get(idx)
+        if self.side is None:
+            self.side = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+        self.main = torch.cuda.current_stream(idx)
+        self.prev = None          # Block backwards never nest; a list left behind by a failed backward is dropped
+        _DEFERRED_DONE = []
+
+    def __call__(self, fn, *args, **kw):
+        """Run fn(*args) on the side stream, after what the main stream holds now."""
+        if not self.on:
+            return fn(*args, **kw)
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            return fn(*args, **kw)
+
+    def join(self):
+        if not self.on:
+            return
+        global _DEFERRED_DONE
+        self.main.wait_stream(self.side)
+        done, _DEFERRED_DONE = _DEFERRED_DONE, self.prev
+        for p in done:
+            grad_done(p)
 
 
 def wgrad(dy, lddy, x, ldx, rows_out, cols_out, k_tokens, row_seg=(0, 0), col_seg=(0, 0), m_phys=None, n_phys=None, param=None):
@@ -257,33 +311,36 @@ class _BlockFn(torch.autograd.Function):
         sh = blk.shadows()
         dx2 = dx2.contiguous().view(M, Dp)
         dyb = ops.cast_bf16(dx2, Dp, M, D, Dp)
-        # ---- MLP
+        side = _SideStream(x.device)
+        # ---- MLP (weight / bias gradients beside the dgrad chain, see _SideStream)
         a, mlp = blk.attn, blk.mlp
-        d_fc2w = wgrad(dyb, Dp, g, dm.Hp, D, dm.hidden, M, param=mlp.fc2.weight)
-        d_fc2b = bgrad(dyb, Dp, M, D, param=mlp.fc2.bias)
+        d_fc2w = side(wgrad, dyb, Dp, g, dm.Hp, D, dm.hidden, M, param=mlp.fc2.weight)
+        d_fc2b = side(bgrad, dyb, Dp, M, D, param=mlp.fc2.bias)
         du = torch.empty(M, dm.Hp, dtype=torch.bfloat16, device=x.device)   # GELU'(pre-activation), saved for backward
         ops.gemm(dyb, sh["fc2_w"], du, M, dm.Hp, Dp, Dp, dm.Hp, dm.Hp, b_layout=1, epilogue=ops.EPI_GELU_BWD, aux_in=u,
                  ld_aux=dm.Hp, flops=2.0 * M * D * dm.hidden)
-        d_fc1w = wgrad(du, dm.Hp, ln2, Dp, dm.hidden, D, M, param=mlp.fc1.weight)
-        d_fc1b = bgrad(du, dm.Hp, M, dm.hidden, param=mlp.fc1.bias)
+        d_fc1w = side(wgrad, du, dm.Hp, ln2, Dp, dm.hidden, D, M, param=mlp.fc1.weight)
+        d_fc1b = side(bgrad, du, dm.Hp, M, dm.hidden, param=mlp.fc1.bias)
         dln2 = torch.empty(M, Dp, dtype=torch.bfloat16, device=x.device)
         ops.gemm(du, sh["fc1_w"], dln2, M, Dp, dm.Hp, dm.Hp, Dp, Dp, b_layout=1, flops=2.0 * M * D * dm.hidden)
-        del du
+        if not side.on:
+            del du
         dx1, dx1b, d_n2w, d_n2b = ops.layernorm_bwd(dln2, Dp, x1, Dp, n2w, mean2, rstd2, M, D, Dp, dx_in=dx2,
                                                     want_bf16=True, ld_dxb=Dp)
         # ---- attention
-        d_projw = wgrad(dx1b, Dp, o, dm.AO, D, D, M, col_seg=(dm.hdp, dm.hd), n_phys=dm.AO, param=a.proj.weight)
-        d_projb = bgrad(dx1b, Dp, M, D, param=a.proj.bias)
+        d_projw = side(wgrad, dx1b, Dp, o, dm.AO, D, D, M, col_seg=(dm.hdp, dm.hd), n_phys=dm.AO, param=a.proj.weight)
+        d_projb = side(bgrad, dx1b, Dp, M, D, param=a.proj.bias)
         do = torch.empty(M, dm.AO, dtype=torch.bfloat16, device=x.device)
         ops.gemm(dx1b, sh["proj_w"], do, M, dm.AO, Dp, Dp, dm.AO, dm.AO, b_layout=1, flops=2.0 * M * D * D)
         dqkv = attention_bwd(do, qkv, o, ctx.att_saved, B, N, dm)
-        d_qkvw = wgrad(dqkv, dm.QKV, ln1, Dp, 3 * D, D, M, row_seg=(dm.hdp, dm.hd), m_phys=dm.QKV, param=a.qkv.weight)
+        d_qkvw = side(wgrad, dqkv, dm.QKV, ln1, Dp, 3 * D, D, M, row_seg=(dm.hdp, dm.hd), m_phys=dm.QKV, param=a.qkv.weight)
         d_qkvb = None
         if blk.attn.qkv.bias is not None:
-            d_qkvb = ops.unpack_vec(ops.colsum(dqkv, dm.QKV, M, dm.QKV), 3 * D, seg=(dm.hdp, dm.hd))
+            d_qkvb = side(lambda: ops.unpack_vec(ops.colsum(dqkv, dm.QKV, M, dm.QKV), 3 * D, seg=(dm.hdp, dm.hd)))
         dln1 = torch.empty(M, Dp, dtype=torch.bfloat16, device=x.device)
         ops.gemm(dqkv, sh["qkv_w"], dln1, M, Dp, dm.QKV, dm.QKV, Dp, Dp, b_layout=1, flops=6.0 * M * D * D)
         dx, _, d_n1w, d_n1b = ops.layernorm_bwd(dln1, Dp, x, Dp, n1w, mean1, rstd1, M, D, Dp, dx_in=dx1)
+        side.join()
         return (dx.view(B, N, Dp), None, d_n1w, d_n1b, d_qkvw, d_qkvb, d_projw, d_projb, d_n2w, d_n2b, d_fc1w, d_fc1b,
                 d_fc2w, d_fc2b)
 
