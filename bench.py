@@ -266,7 +266,9 @@ def main():
                 out["roofline"]["traffic_unit"] = "HBM bytes per launch"
                 out["roofline"]["traffic_source"] = "profiles/" + src
             out["kernels"] = {k: {"ms_per_step": round(v[0] / args.steps * 1e3, 3),
-                                  "tflops": round(v[1] / v[0] / 1e12, 1), "launches_per_step": v[2] // args.steps}
+                                  "tflops": round(v[1] / v[0] / 1e12, 1),
+                                  "mfma_frac": round(v[1] / v[0] / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                  "launches_per_step": v[2] // args.steps}
                               for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
         if world == 1 and not args.no_cpu_baseline and wl == "stage1":
             cdt, ctf, cores = cpu_baseline(args.cpu_frames)

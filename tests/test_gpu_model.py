@@ -195,6 +195,48 @@ def test_block_reference_dims(N):
         assert rel(v.grad, leaves[k].grad) < 2e-2, k
 
 
+def test_block_backward_side_stream_matches_single_stream():
+    """Weight / bias gradients launched on the second HIP stream (vita_amd.nn._SideStream) equal the single-stream
+    ones, both returned through autograd and accumulated in place into an existing fp32 .grad (split-K atomics:
+    summation order differs, hence 1e-5), and every in-place gradient still reports through GRAD_READY after the join."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from vita_amd import nn as vnn
+    D, H, B, N = 1025, 5, 2, 300
+    torch.manual_seed(3)
+    blk = vnn.Block(D, H, 4.0, qkv_bias=True).cuda()
+    x = torch.randn(B, N, D, device="cuda")
+    cot = torch.randn(B, N, D, device="cuda")
+
+    def run(side, inplace):
+        old = vnn.WGRAD_SIDE_STREAM
+        vnn.WGRAD_SIDE_STREAM = side
+        reported = []
+        try:
+            for p in blk.parameters():
+                p.grad = torch.zeros_like(p) if inplace else None
+                if inplace:
+                    vnn.GRAD_READY[id(p)] = lambda q: reported.append(id(q))
+            xg = x.clone().requires_grad_(True)
+            (blk(xg) * cot).sum().backward()
+            torch.cuda.synchronize()
+            return {k: v.grad.clone() for k, v in blk.named_parameters()}, xg.grad.clone(), reported
+        finally:
+            vnn.WGRAD_SIDE_STREAM = old
+            vnn.GRAD_READY.clear()
+
+    g0, dx0, _ = run(False, False)
+    for inplace in (False, True):
+        g1, dx1, rep = run(True, inplace)
+        assert torch.equal(dx0, dx1)
+        for k in g0:
+            assert rel(g1[k], g0[k]) < 1e-5, (k, inplace)
+        if inplace:      # the eight Linear weights / biases minus the qkv bias (returned through autograd)
+            want = {id(p) for n, p in blk.named_parameters() if "norm" not in n and n != "attn.qkv.bias"}
+            assert want <= set(rep)
+    assert vnn._DEFERRED_DONE is None
+
+
 def test_clip_loss_golden(golden):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")

@@ -513,63 +513,60 @@ extern "C" int vita_cast_f32_bf16(const float* x, int64_t ldx, void* y, int64_t 
   return VITA_OK;
 }
 
-// each thread owns 2 adjacent columns; grid.y row chunks; fp32 atomics into a zeroed output
-// 16-byte loads (8 bf16 / 4 fp32 columns per lane), the block's 4 waves take interleaved rows of the block's
-// row range (4 rows in flight per wave), LDS reduce over the waves, one atomic per column and block.
+// Column sums (bias gradients).  A block is 16 column lanes x 16 row lanes: a column lane owns one 16-byte unit (8 bf16 /
+// 4 fp32 columns), so a block covers 128 / 64 columns and a wave-load fetches 4 rows x 256 contiguous bytes.  Each thread
+// keeps 8 independent 16-B loads in flight over the rows r0 + rl + 16 i of the block's row chunk (the kernel is latency-
+// bound: a narrow matrix gives few blocks, so the bytes in flight per thread are what reaches the HBM rate), the 16 row
+// lanes are reduced through LDS and every column ends in ONE fp32 atomic per block.
 template <bool F32>
 __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, int64_t ld, int64_t rows, int64_t cols,
                                                      float* __restrict__ out, int64_t rows_per_blk) {
-  constexpr int CPT = F32 ? 4 : 8;
-  __shared__ float red[4][64 * CPT];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t c = ((int64_t)blockIdx.x * 64 + lane) * CPT;
+  constexpr int CPT = F32 ? 4 : 8, U = 8;
+  __shared__ float red[16][16 * CPT + 4];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int64_t c = ((int64_t)blockIdx.x * 16 + cl) * CPT;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_blk;
   int64_t r1 = r0 + rows_per_blk; if (r1 > rows) r1 = rows;
   float acc[CPT];
 #pragma unroll
   for (int j = 0; j < CPT; ++j) acc[j] = 0.f;
+  auto add = [&](const u32x4 v) {
+    if constexpr (F32) {
+      const f32x4 vf = __builtin_bit_cast(f32x4, v);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += vf[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[2 * j] += __builtin_bit_cast(float, v[j] << 16);
+        acc[2 * j + 1] += __builtin_bit_cast(float, v[j] & 0xffff0000u);
+      }
+    }
+  };
   if (c < cols) {
     const char* base = (const char*)x + c * (F32 ? 4 : 2);
     const int64_t rb = ld * (F32 ? 4 : 2);
-    int64_t r = r0 + wave;
-    for (; r + 12 < r1; r += 16) {
-      u32x4 v[4];
+    int64_t r = r0 + rl;
+    for (; r + 16 * (U - 1) < r1; r += 16 * U) {
+      u32x4 v[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const u32x4*>(base + (r + 4 * u) * rb);
+      for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + (r + 16 * u) * rb));
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if constexpr (F32) {
-          { const f32x4 vf = __builtin_bit_cast(f32x4, v[u]); acc[0] += vf[0]; acc[1] += vf[1]; acc[2] += vf[2]; acc[3] += vf[3]; }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            acc[2 * j] += __builtin_bit_cast(float, v[u][j] << 16);
-            acc[2 * j + 1] += __builtin_bit_cast(float, v[u][j] & 0xffff0000u);
-          }
-        }
-      }
+      for (int u = 0; u < U; ++u) add(v[u]);
     }
-    for (; r < r1; r += 4) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(base + r * rb);
-      if constexpr (F32) {
-        { const f32x4 vf = __builtin_bit_cast(f32x4, v); acc[0] += vf[0]; acc[1] += vf[1]; acc[2] += vf[2]; acc[3] += vf[3]; }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[2 * j] += __builtin_bit_cast(float, v[j] << 16);
-          acc[2 * j + 1] += __builtin_bit_cast(float, v[j] & 0xffff0000u);
-        }
-      }
-    }
+    for (; r < r1; r += 16) add(*reinterpret_cast<const u32x4*>(base + r * rb));
   }
 #pragma unroll
-  for (int j = 0; j < CPT; ++j) red[wave][j * 64 + lane] = acc[j];
+  for (int j = 0; j < CPT; ++j) red[rl][cl * CPT + j] = acc[j];
   __syncthreads();
-  // thread t sums column slot t of the 4 waves: slot = j*64 + lane  ->  column c(lane) + j
-  for (int sidx = threadIdx.x; sidx < 64 * CPT; sidx += 256) {
-    const int j = sidx >> 6, l = sidx & 63;
-    const int64_t col = ((int64_t)blockIdx.x * 64 + l) * CPT + j;
-    if (col < cols) atomicAdd(out + col, red[0][sidx] + red[1][sidx] + red[2][sidx] + red[3][sidx]);
+  if (threadIdx.x < 16 * CPT) {
+    const int64_t col = (int64_t)blockIdx.x * 16 * CPT + threadIdx.x;
+    if (col < cols) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+      atomicAdd(out + col, t);
+    }
   }
 }
 static int colsum_impl(const void* x, int32_t dtype, int64_t ld, int64_t rows, int64_t cols, float* out, bool zero, void* stream);
@@ -585,12 +582,12 @@ static int colsum_impl(const void* x, int32_t dtype, int64_t ld, int64_t rows, i
   VITA_REQUIRE(x && out && rows > 0 && cols > 0 && ld % cpt == 0 && ld >= ((cols + cpt - 1) / cpt) * cpt);
   VITA_REQUIRE(((uintptr_t)x & 15) == 0);
   if (zero && hipMemsetAsync(out, 0, cols * sizeof(float), (hipStream_t)stream) != hipSuccess) return VITA_ERR_LAUNCH;
-  const int64_t colblk = (cols + 64 * cpt - 1) / (64 * cpt);
-  // about 2048 blocks in all, at least 64 rows per block, at most 256 row chunks: every chunk ends in one fp32 atomic
-  // per column, and a narrow matrix (few column blocks) otherwise spends its time serialising them
+  const int64_t colblk = (cols + 16 * cpt - 1) / (16 * cpt);
+  // about 2048 blocks in all (8 per CU), at least 128 rows per block (one batch of 8 loads per thread), at most 256 row
+  // chunks: every chunk ends in one fp32 atomic per column
   int64_t chunks = (2048 + colblk - 1) / colblk;
   if (chunks > 256) chunks = 256;
-  if (chunks > (rows + 63) / 64) chunks = (rows + 63) / 64;
+  if (chunks > (rows + 127) / 128) chunks = (rows + 127) / 128;
   if (chunks < 1) chunks = 1;
   const int64_t rpb = (rows + chunks - 1) / chunks;
   dim3 grid((unsigned)colblk, (unsigned)chunks);

@@ -266,6 +266,8 @@ def attn_bwd(qkv, o, do, lse, dqkv, B, N, H, hd, hdp, scale, handoff=None):
     if ATTN_DS_HANDOFF if handoff is None else handoff:
         ws_bytes = _lib.lib().vita_attn_bwd_ws_bytes(B, N, H, hdp)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=qkv.device)
-    with _Timed("attn_bwd_kernels", 10.0 * B * H * N * N * hd):
+    # algorithmic work = the four products the reference's backward performs (dV, dP, dQ, dK: 2x the forward,
+    # SURVEY 8(d) "step = 3x fwd"); the S recompute of the fused kernels is overhead, not counted
+    with _Timed("attn_bwd_kernels", 8.0 * B * H * N * N * hd):
         check(_lib.lib().vita_attn_bwd(qkv.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(), delta.data_ptr(),
                                        dqkv.data_ptr(), _p(ws), ws_bytes, B, N, H, hd, hdp, scale, _s()), "attn_bwd")
