@@ -25,6 +25,31 @@ for r in stats[:16]:
     frs = f"{2 * fr[0] * 1024 / fr[1] / 1e6:.1f}" if fr and fr[1] else "-"
     wrs = f"{wr[0] * 1024 / wr[1] / 1e6:.1f}" if wr and wr[1] else "-"
     lines.append(f"| `{n[:70]}` | {r['Calls']} | {int(r['TotalDurationNs']) / steps / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.1f} | {r['Percentage']} | {frs} | {wrs} |")
+# MFMA utilisation from the SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE pass (kernels run one at a time under --pmc).
+# busy % = MFMA busy cycles summed over the SIMDs / (kernel cycles x 1024 SIMDs); kernel cycles = GRBM_GUI_ACTIVE / 8
+# (rocprofv3 reports the sum over the 8 XCDs, MI355X_MICROARCH.md "DVFS give-back"); clock = cycles / wall time.
+mf = glob.glob(f"{src}/pmc_mfma/*/*_counter_collection.csv")
+if mf:
+    disp = collections.defaultdict(dict)
+    for r in csv.DictReader(open(mf[0])):
+        d = disp[r["Dispatch_Id"]]
+        d["name"], d["grid"] = r["Kernel_Name"], r["Grid_Size"]
+        d["ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    agg = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])
+    for d in disp.values():
+        if "SQ_VALU_MFMA_BUSY_CYCLES" not in d or not d.get("GRBM_GUI_ACTIVE"): continue
+        a = agg[(d["name"], d["grid"])]
+        a[0] += 1; a[1] += d["ns"]; a[2] += d["SQ_VALU_MFMA_BUSY_CYCLES"]; a[3] += d["GRBM_GUI_ACTIVE"] / 8.0
+    lines += ["", "MFMA utilisation per kernel and grid (PMC pass, kernels serialised):", "",
+              "| kernel | grid (threads) | launches | avg us | MFMA busy % of kernel cycles | in-kernel clock GHz | MFMA busy % of 2.4 GHz wall |", "|---|---|---|---|---|---|---|"]
+    mfma_json = {}
+    for (n, g), a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        if a[2] <= 0 or a[1] / steps < 2e5: continue
+        busy = 100.0 * a[2] / (a[3] * 1024.0); clk = a[3] / a[1]
+        lines.append(f"| `{n[:60]}` | {g} | {a[0]} | {a[1] / a[0] / 1e3:.1f} | {busy:.1f} | {clk:.2f} | {busy * clk / 2.4:.1f} |")
+        mfma_json[f"{n[:60]}|{g}"] = {"launches": a[0], "avg_us": a[1] / a[0] / 1e3, "mfma_busy_pct": busy, "clock_ghz": clk}
+    json.dump(mfma_json, open(f"profiles/{tag}_mfma_util.json", "w"), indent=1, sort_keys=True)
 log = [l for l in open(f"{src}/trace.log").read().splitlines() if l.startswith('{"metric"')]
 js = {}
 try:

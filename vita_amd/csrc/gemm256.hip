@@ -302,6 +302,12 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(const Gemm2Param
   const float alpha = d.alpha;
   const int ncol = nfw * 16;
   const int64_t nw0 = n0 + wn * NFW * 16;
+  // bf16 C (and bf16 aux) with 16-B aligned rows: the wide-store epilogue (uniform over the launch)
+  const bool wide_bf16 = !ATOMIC && d.c_dtype == VITA_DT_BF16 && d.epilogue != VITA_EPI_RESIDUAL && (d.n & 7) == 0 && (d.ldc & 7) == 0 &&
+                         ((uintptr_t)d.c & 15) == 0 && (d.bias == nullptr || ((uintptr_t)d.bias & 15) == 0) &&
+                         (d.epilogue == VITA_EPI_NONE ||
+                          (d.epilogue == VITA_EPI_GELU && ((uintptr_t)d.aux_out & 15) == 0) ||
+                          (d.epilogue == VITA_EPI_GELU_BWD && (d.ld_aux & 7) == 0 && ((uintptr_t)d.aux_in & 15) == 0));
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     if (ATOMIC) {
@@ -353,6 +359,58 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(const Gemm2Param
           }
         }
         if (d.row_seg_phys) { if (++rr == d.row_seg_phys) { rr = 0; ++rq; } }
+      }
+    } else if (wide_bf16) {
+      // bf16 output, 16-B stores: a lane owns 8 columns, a wave-instruction writes 4 rows x 16 lanes x 16 B.  The
+      // epilogue is bound by the CU's store ISSUE rate (MI355X_MICROARCH.md, store tail), so half as many store
+      // instructions as the 8-B form below is half the tail.
+      const int c8 = lane & 15;
+      const int64_t n = nw0 + c8 * 8;
+      const bool okc = c8 * 8 < ncol && n < d.n;      // d.n % 8 == 0 on this path
+      const int64_t nl = okc ? n : 0;
+      f32x4 bv0 = f32x4{0.f, 0.f, 0.f, 0.f}, bv1 = bv0;
+      if (okc && d.bias) { bv0 = *reinterpret_cast<const f32x4*>(d.bias + n); bv1 = *reinterpret_cast<const f32x4*>(d.bias + n + 4); }
+      auto runw = [&](auto tag) {
+        constexpr int EPI = decltype(tag)::value;
+        u32x4 ux[8];
+        if (EPI == VITA_EPI_GELU_BWD) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            int64_t m = mrow0 + 4 * u + (lane >> 4);
+            if (m >= d.m) m = d.m - 1;
+            ux[u] = *reinterpret_cast<const u32x4*>((const uint16_t*)d.aux_in + m * d.ld_aux + nl);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int row = 4 * u + (lane >> 4);
+          const int64_t m = mrow0 + row;
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + row * RS + c8 * 8) * alpha + bv0;
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + row * RS + c8 * 8 + 4) * alpha + bv1;
+          float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+          const bool ok = okc && m < d.m;
+          const int64_t o = m * d.ldc + n;
+          if (EPI == VITA_EPI_GELU) {
+            float dg[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { float g, dgr; gelu_erf_both(v[r], g, dgr); v[r] = g; dg[r] = dgr; }
+            if (ok) *reinterpret_cast<u32x4*>((uint16_t*)d.aux_out + o) =
+                u32x4{pack_bf16x2(dg[0], dg[1]), pack_bf16x2(dg[2], dg[3]), pack_bf16x2(dg[4], dg[5]), pack_bf16x2(dg[6], dg[7])};
+          } else if (EPI == VITA_EPI_GELU_BWD) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[2 * r] *= __builtin_bit_cast(float, ux[u][r] << 16);
+              v[2 * r + 1] *= __builtin_bit_cast(float, ux[u][r] & 0xffff0000u);
+            }
+          }
+          if (ok) *reinterpret_cast<u32x4*>((uint16_t*)d.c + o) =
+              u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+        }
+      };
+      switch (d.epilogue) {
+        case VITA_EPI_GELU: runw(std::integral_constant<int, VITA_EPI_GELU>{}); break;
+        case VITA_EPI_GELU_BWD: runw(std::integral_constant<int, VITA_EPI_GELU_BWD>{}); break;
+        default: runw(std::integral_constant<int, VITA_EPI_NONE>{}); break;
       }
     } else {
       const int c4 = lane & 31;
