@@ -270,6 +270,8 @@ def main():
                                   "mfma_frac": round(v[1] / v[0] / 1e12 / PEAK_BF16_TFLOPS, 4),
                                   "launches_per_step": v[2] // args.steps}
                               for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}
+            out["kernels_note"] = ("HIP-event time per launch group; weight-gradient GEMMs (<1,1>) run on a second stream beside the "
+                                   "dgrad GEMMs (<0,1>) in the backward, so those two groups overlap and their times are not additive")
         if world == 1 and not args.no_cpu_baseline and wl == "stage1":
             cdt, ctf, cores = cpu_baseline(args.cpu_frames)
             out["cpu_baseline"] = {"value": round(ctf * 1e12 / step_fl, 6), "unit": "subjects/s", "cores": cores, "kind": "port",
