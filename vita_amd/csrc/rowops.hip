@@ -271,31 +271,52 @@ __device__ __forceinline__ uint32_t float_key(float f) {
   const uint32_t u = __builtin_bit_cast(uint32_t, f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
-__global__ __launch_bounds__(256) void argsort_rank_kernel(const float* __restrict__ noise, int l, int len_keep,
-                                                           int64_t* __restrict__ ids_shuffle,
-                                                           int64_t* __restrict__ ids_restore, float* __restrict__ mask) {
+// A block of 16 waves ranks 256 keys: the four waves of quarter q count over the q-th quarter of the row (every lane of
+// a wave reads the same LDS address: a broadcast), the four partial counts meet in LDS.  The row is brought into LDS
+// once per block with 16-B loads; 4 waves per SIMD hide the LDS latency of this VALU-bound O(l^2) count.
+#define ARGSORT_THREADS 1024
+__global__ __launch_bounds__(ARGSORT_THREADS) void argsort_rank_kernel(const float* __restrict__ noise, int l, int len_keep,
+                                                                       int64_t* __restrict__ ids_shuffle,
+                                                                       int64_t* __restrict__ ids_restore, float* __restrict__ mask) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int part[4][256];
   uint32_t* keys = reinterpret_cast<uint32_t*>(smem);
   const int row = blockIdx.y;
   const float* nr = noise + (int64_t)row * l;
   const int lp = (l + 3) & ~3;
-  for (int j = threadIdx.x; j < lp; j += 256) keys[j] = j < l ? float_key(nr[j]) : 0xffffffffu;
+  if ((l & 3) == 0 && (((uintptr_t)nr) & 15) == 0) {
+    for (int j4 = threadIdx.x; j4 < (l >> 2); j4 += ARGSORT_THREADS) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(nr + 4 * j4);
+      *reinterpret_cast<u32x4*>(keys + 4 * j4) = u32x4{float_key(v[0]), float_key(v[1]), float_key(v[2]), float_key(v[3])};
+    }
+  } else {
+    for (int j = threadIdx.x; j < lp; j += ARGSORT_THREADS) keys[j] = j < l ? float_key(nr[j]) : 0xffffffffu;
+  }
   __syncthreads();
-  const int i0 = blockIdx.x * 256, i = i0 + threadIdx.x;
+  const int il = threadIdx.x & 255, q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+  const int i0 = blockIdx.x * 256, i = i0 + il;
   const uint32_t ki = i < l ? keys[i] : 0u;
+  // this quarter [q0, q1) of the row, in units of 4 keys
+  const int per = ((lp >> 2) + 3) / 4;
+  int q0 = q * per * 4, q1 = q0 + per * 4; if (q1 > lp) q1 = lp; if (q0 > lp) q0 = lp;
+  // [q0, jb): j < every i of this block, [je, q1): j > every i of this block, [jb, je): the block's own keys
+  int jb = i0, je = i0 + 256;
+  if (jb < q0) jb = q0; if (jb > q1) jb = q1;
+  if (je < jb) je = jb; if (je > q1) je = q1;
   int cnt = 0;
-  const int jb = i0 & ~3;                              // [0, jb): j < every i of this block
-  int je = (i0 + 256 + 3) & ~3; if (je > lp) je = lp;   // [je, lp): j > every i of this block
-  for (int j = 0; j < jb; j += 4) {
+  for (int j = q0; j < jb; j += 4) {
     const u32x4 k4 = *reinterpret_cast<const u32x4*>(keys + j);
     cnt += (k4[0] <= ki) + (k4[1] <= ki) + (k4[2] <= ki) + (k4[3] <= ki);
   }
   for (int j = jb; j < je; ++j) { const uint32_t kj = keys[j]; cnt += (kj < ki) || (kj == ki && j < i); }
-  for (int j = je; j < lp; j += 4) {
+  for (int j = je; j < q1; j += 4) {
     const u32x4 k4 = *reinterpret_cast<const u32x4*>(keys + j);
     cnt += (k4[0] < ki) + (k4[1] < ki) + (k4[2] < ki) + (k4[3] < ki);
   }
-  if (i < l) {
+  part[q][il] = cnt;
+  __syncthreads();
+  if (q == 0 && i < l) {
+    cnt = part[0][il] + part[1][il] + part[2][il] + part[3][il];
     ids_restore[(int64_t)row * l + i] = cnt;
     ids_shuffle[(int64_t)row * l + cnt] = i;
     mask[(int64_t)row * l + i] = cnt < len_keep ? 0.f : 1.f;
@@ -309,7 +330,7 @@ extern "C" int vita_argsort_mask(const float* noise, int64_t n, int64_t l, int64
   const size_t lds = (size_t)((l + 3) & ~3) * 4;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)argsort_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr = true; }
-  hipLaunchKernelGGL(argsort_rank_kernel, dim3((unsigned)((l + 255) / 256), (unsigned)n), dim3(256), lds, (hipStream_t)stream,
+  hipLaunchKernelGGL(argsort_rank_kernel, dim3((unsigned)((l + 255) / 256), (unsigned)n), dim3(ARGSORT_THREADS), lds, (hipStream_t)stream,
                      noise, (int)l, (int)len_keep, ids_shuffle, ids_restore, mask);
   VITA_CHECK_LAUNCH("vita_argsort_mask");
   return VITA_OK;

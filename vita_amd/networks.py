@@ -19,7 +19,7 @@ from torch import nn
 from torch.utils.checkpoint import checkpoint
 
 from . import ops
-from .nn import Block, Dims, _Shadows, _require_cuda, layer_norm_padded, linear_padded, pad_tokens, wgrad
+from .nn import Block, Dims, _Shadows, _require_cuda, bf16_twin, layer_norm_padded, linear_padded, pad_tokens, wgrad
 
 __all__ = ["PatchEmbed", "Masker", "sincos_pos_embed", "ImagingMaskedEncoder", "ViTDecoder", "ImagingMaskedDecoder",
            "TabularViT", "SimCLRProjectionHead"]
@@ -106,8 +106,10 @@ class _TokenizeFn(torch.autograd.Function):
         (cols,) = ctx.saved_tensors
         B, n, D, Dp, P, Pp, with_cls, wshape, has_b = ctx.meta
         rows = cols.shape[0]
+        dyb = bf16_twin(dout, rows, Dp)
         dout = dout.contiguous().view(rows, Dp)
-        dyb = ops.cast_bf16(dout, Dp, rows, D, Dp)
+        if dyb is None:
+            dyb = ops.cast_bf16(dout, Dp, rows, D, Dp)
         dw = wgrad(dyb, Dp, cols, Pp, D, P, rows).reshape(wshape)
         db = ops.colsum(dyb, Dp, rows, D) if has_b else None
         dcls = None

@@ -271,6 +271,22 @@ def bgrad(dy, ld, rows, cols, param=None):
     return ops.colsum(dy, ld, rows, cols)
 
 
+def with_bf16_twin(g, gb):
+    """Attach the bf16 copy a kernel wrote beside an fp32 gradient (LayerNorm backward emits both in one pass).  The
+    next backward node gets the very tensor object its producer returned when the two are chained directly, and then
+    skips its own fp32 -> bf16 cast pass; anything in between (gradient accumulation, a checkpoint boundary) hands over
+    a different object without the attribute, and the consumer casts as before."""
+    g._vita_bf16 = gb
+    return g
+
+
+def bf16_twin(g, rows, ld):
+    gb = getattr(g, "_vita_bf16", None)
+    if gb is None or not g.is_contiguous() or tuple(gb.shape) != (rows, ld) or gb.device != g.device:
+        return None
+    return gb
+
+
 # ----------------------------------------------------------------------------- Block
 class _BlockFn(torch.autograd.Function):
     @staticmethod
@@ -309,8 +325,10 @@ class _BlockFn(torch.autograd.Function):
         M, Dp, D = B * N, dm.Dp, dm.D
         x, mean1, rstd1, ln1, qkv, o, x1, mean2, rstd2, ln2, u, g, n1w, n2w = ctx.saved_tensors
         sh = blk.shadows()
+        dyb = bf16_twin(dx2, M, Dp)
         dx2 = dx2.contiguous().view(M, Dp)
-        dyb = ops.cast_bf16(dx2, Dp, M, D, Dp)
+        if dyb is None:
+            dyb = ops.cast_bf16(dx2, Dp, M, D, Dp)
         side = _SideStream(x.device)
         # ---- MLP (weight / bias gradients beside the dgrad chain, see _SideStream)
         a, mlp = blk.attn, blk.mlp
@@ -339,9 +357,11 @@ class _BlockFn(torch.autograd.Function):
             d_qkvb = side(lambda: ops.unpack_vec(ops.colsum(dqkv, dm.QKV, M, dm.QKV), 3 * D, seg=(dm.hdp, dm.hd)))
         dln1 = torch.empty(M, Dp, dtype=torch.bfloat16, device=x.device)
         ops.gemm(dqkv, sh["qkv_w"], dln1, M, Dp, dm.QKV, dm.QKV, Dp, Dp, b_layout=1, flops=6.0 * M * D * D)
-        dx, _, d_n1w, d_n1b = ops.layernorm_bwd(dln1, Dp, x, Dp, n1w, mean1, rstd1, M, D, Dp, dx_in=dx1)
+        dx, dxb, d_n1w, d_n1b = ops.layernorm_bwd(dln1, Dp, x, Dp, n1w, mean1, rstd1, M, D, Dp, dx_in=dx1, want_bf16=True,
+                                                  ld_dxb=Dp)
         side.join()
-        return (dx.view(B, N, Dp), None, d_n1w, d_n1b, d_qkvw, d_qkvb, d_projw, d_projb, d_n2w, d_n2b, d_fc1w, d_fc1b,
+        dx = with_bf16_twin(dx.view(B, N, Dp), dxb)
+        return (dx, None, d_n1w, d_n1b, d_qkvw, d_qkvb, d_projw, d_projb, d_n2w, d_n2b, d_fc1w, d_fc1b,
                 d_fc2w, d_fc2b)
 
 
@@ -420,8 +440,8 @@ class _LayerNormFn(torch.autograd.Function):
         x, w, mean, rstd = ctx.saved_tensors
         B, N, Dp = dy.shape
         dy = dy.contiguous().view(B * N, Dp)
-        dx, _, dw, db = ops.layernorm_bwd(dy, Dp, x, Dp, w, mean, rstd, B * N, ctx.D, Dp)
-        return dx.view(B, N, Dp), dw, db, None, None
+        dx, dxb, dw, db = ops.layernorm_bwd(dy, Dp, x, Dp, w, mean, rstd, B * N, ctx.D, Dp, want_bf16=True, ld_dxb=Dp)
+        return with_bf16_twin(dx.view(B, N, Dp), dxb), dw, db, None, None
 
 
 def layer_norm_padded(xp, ln: nn.LayerNorm):
