@@ -108,7 +108,7 @@ extern "C" int vita_layernorm_fwd(const float* x, int64_t ldx, const float* gamm
   return VITA_OK;
 }
 
-#define LN_BWD_MAXBLK 1024
+#define LN_BWD_MAXBLK 768     // 3 blocks (12 waves, 167 VGPRs each) are resident per CU: 256 x 3 = one full round
 extern "C" int64_t vita_layernorm_bwd_nblk(int64_t rows) {
   int64_t n = (rows + 15) / 16;      // at least 4 rows per wave: the per-block partial reduction is not free
   return n < LN_BWD_MAXBLK ? n : LN_BWD_MAXBLK;
