@@ -447,19 +447,32 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restr
   if (row >= BN) return;
   const int64_t b = row / N, q = row % N;
   const int cpr = HDP / 4;
-  for (int h = 0; h < H; ++h) {
-    float acc = 0.f;
+  // four heads in flight per wave: the eight loads of a group are issued before the first product (the heads used to go
+  // one after the other, each with its own load -> reduce dependency)
+  for (int h0 = 0; h0 < H; h0 += 4) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c = lane; c < cpr; c += 64) {
-      const u32x2 a = *reinterpret_cast<const u32x2*>(o + (row * H + h) * HDP + c * 4);
-      const u32x2 d = *reinterpret_cast<const u32x2*>(dout + (row * H + h) * HDP + c * 4);
-      acc += bf16_bits_to_f32((uint16_t)(a[0] & 0xffff)) * bf16_bits_to_f32((uint16_t)(d[0] & 0xffff));
-      acc += bf16_bits_to_f32((uint16_t)(a[0] >> 16)) * bf16_bits_to_f32((uint16_t)(d[0] >> 16));
-      acc += bf16_bits_to_f32((uint16_t)(a[1] & 0xffff)) * bf16_bits_to_f32((uint16_t)(d[1] & 0xffff));
-      acc += bf16_bits_to_f32((uint16_t)(a[1] >> 16)) * bf16_bits_to_f32((uint16_t)(d[1] >> 16));
+      u32x2 a[4], d[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int h = h0 + j < H ? h0 + j : H - 1;
+        a[j] = *reinterpret_cast<const u32x2*>(o + (row * H + h) * HDP + c * 4);
+        d[j] = *reinterpret_cast<const u32x2*>(dout + (row * H + h) * HDP + c * 4);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[j] += bf16_bits_to_f32((uint16_t)(a[j][0] & 0xffff)) * bf16_bits_to_f32((uint16_t)(d[j][0] & 0xffff));
+        acc[j] += bf16_bits_to_f32((uint16_t)(a[j][0] >> 16)) * bf16_bits_to_f32((uint16_t)(d[j][0] >> 16));
+        acc[j] += bf16_bits_to_f32((uint16_t)(a[j][1] & 0xffff)) * bf16_bits_to_f32((uint16_t)(d[j][1] & 0xffff));
+        acc[j] += bf16_bits_to_f32((uint16_t)(a[j][1] >> 16)) * bf16_bits_to_f32((uint16_t)(d[j][1] >> 16));
+      }
     }
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      ld2[((b * H + h) * 2 + 1) * N + q] = acc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = wave_sum(acc[j]);
+    if (lane < 4 && h0 + lane < H) {
+      const int h = h0 + lane;
+      const float v = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
+      ld2[((b * H + h) * 2 + 1) * N + q] = v;
       ld2[((b * H + h) * 2) * N + q] = lse[(b * H + h) * N + q] * -1.4426950408889634f;   // -lse * log2(e)
     }
   }
