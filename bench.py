@@ -207,6 +207,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    t_issued = time.perf_counter() - t0       # host done issuing; close to dt when the host, not the GPU, sets the pace
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -247,6 +248,7 @@ def main():
                        "parallelism": f"dp{world}", "loss": round(float(loss.detach()), 6)},
             "step_tflop_per_subject": round(step_fl / 1e12, 3),
             "model_tflops_per_gpu": round(step_fl * B * args.steps / dt / 1e12, 1),
+            "host_issue_ms_per_step": round(t_issued / args.steps * 1e3, 3),
         }
         if prof:
             agg = {}

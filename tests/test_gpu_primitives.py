@@ -346,7 +346,7 @@ def _mk_operand(M, free, k, layout, ld_pad=0):
     return t, ld
 
 
-@pytest.mark.parametrize("variant", [13, 14, 16])
+@pytest.mark.parametrize("variant", [8, 10, 12, 13, 14, 16])
 @pytest.mark.parametrize("la,lb", [(0, 0), (0, 1), (1, 1)])
 @pytest.mark.parametrize("m,n,k", [(256, 224, 64), (700, 1088, 1120), (1000, 420, 200), (513, 3360, 1088), (2500, 1040, 4112)])
 def test_gemm256_layouts(ops, variant, la, lb, m, n, k):
@@ -395,7 +395,7 @@ def test_gemm256_epilogues(ops, variant):
     assert torch.equal(c5.cpu(), 2.0 * Bm)
 
 
-@pytest.mark.parametrize("variant", [13, 14, 16])
+@pytest.mark.parametrize("variant", [8, 10, 12, 13, 14, 16])
 @pytest.mark.parametrize("split_k", [1, 3])
 def test_gemm256_wgrad_maps(ops, variant, split_k):
     """weight-gradient form: dW = dY^T X with head-padded rows un-padded through the segment maps."""

@@ -32,7 +32,7 @@ def run(name, m, n, k, la, lb, variants, out_f32=False, epi=0, split_k=1):
 
 if __name__ == "__main__":
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 13826
-    V = [0, 1, 13, 14, 16]
+    V = [0, 8, 10, 12, 13, 14, 16]
     run("qkv", M, 3360, 1088, 0, 0, V)
     run("proj", M, 1088, 1120, 0, 0, V, out_f32=True, epi=ops.EPI_RESIDUAL)
     run("fc1", M, 4160, 1088, 0, 0, V, epi=ops.EPI_GELU)

@@ -251,7 +251,7 @@ double vita_gemm256_cost(const vita_gemm_desc& d, int* nf_out);
 double vita_gemm128_cost(const vita_gemm_desc& d);
 int vita_gemm256_launch(const vita_gemm_desc& d, int nf, hipStream_t s);
 
-// variant: 0 = choose by shape, 1 = 128x128 kernel, 13 / 14 / 16 = 256 x (16*variant) kernel
+// variant: 0 = choose by shape, 1 = 128x128 kernel, 8 / 10 / 12 / 13 / 14 / 16 = 256 x (16*variant) kernel
 extern "C" int vita_gemm_bf16_ex(const vita_gemm_desc* dp, int32_t variant, void* stream) {
   if (!dp) return VITA_ERR_INVALID_ARG;
   vita_gemm_desc d = *dp;
@@ -287,7 +287,7 @@ extern "C" int vita_gemm_bf16_ex(const vita_gemm_desc* dp, int32_t variant, void
   if (variant != 1) {
     const bool ok = vita_gemm256_supported(d);
     if (variant > 1) {
-      VITA_REQUIRE(ok && (variant == 13 || variant == 14 || variant == 16));
+      VITA_REQUIRE(ok && (variant == 8 || variant == 10 || variant == 12 || variant == 13 || variant == 14 || variant == 16));
       return vita_gemm256_launch(d, variant, (hipStream_t)stream);
     }
     // large un-batched problems: whichever kernel needs fewer (weighted) rounds of workgroups

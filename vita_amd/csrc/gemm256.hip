@@ -23,6 +23,7 @@
 #define G2_BOFF 32768
 #define G2_THREADS 512
 #define G2_OOB 0x7ffffff0u
+#define G2_NARROW_OVERHEAD 3.0   // fixed per-tile cost of the 128..192-column tiles in the cost model's units
 
 struct Gemm2Params {
   vita_gemm_desc d;
@@ -267,16 +268,29 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(const Gemm2Param
       // ---- phase 2: MFMAs of k-step 1; DMA of K-tile t+2 and the reads of (t+1, k-step 0) spread between them
 #pragma unroll
       for (int j = 0; j < NFW; ++j) {
-        if (j == 0) { la.issue(ra, ka, 0, st, wave); la.issue(ra, ka, 1, st, wave); }
-        if (j == 1) la.issue(ra, ka, 2, st, wave);
-        if (j == 2) la.issue(ra, ka, 3, st, wave);
-        if (j == 3) lb.issue(rb, kb, 0, st + G2_BOFF, wave);
-        if (j == 4) lb.issue(rb, kb, 1, st + G2_BOFF, wave);
-        if (j == 5) lb.issue(rb, kb, 2, st + G2_BOFF, wave);
-        if (j == 6) lb.issue(rb, kb, 3, st + G2_BOFF, wave);
-        if (j == 2) { G2_READ_A(0, a0); }
-        if (j == 3) { G2_READ_B(0, b0, 0, 3); }
-        if (j == 4) { G2_READ_B(0, b0, 3, NFW); }
+        if constexpr (NFW >= 7) {
+          if (j == 0) { la.issue(ra, ka, 0, st, wave); la.issue(ra, ka, 1, st, wave); }
+          if (j == 1) la.issue(ra, ka, 2, st, wave);
+          if (j == 2) la.issue(ra, ka, 3, st, wave);
+          if (j == 3) lb.issue(rb, kb, 0, st + G2_BOFF, wave);
+          if (j == 4) lb.issue(rb, kb, 1, st + G2_BOFF, wave);
+          if (j == 5) lb.issue(rb, kb, 2, st + G2_BOFF, wave);
+          if (j == 6) lb.issue(rb, kb, 3, st + G2_BOFF, wave);
+          if (j == 2) { G2_READ_A(0, a0); }
+          if (j == 3) { G2_READ_B(0, b0, 0, 3); }
+          if (j == 4) { G2_READ_B(0, b0, 3, NFW); }
+        } else {
+          // narrow tiles (NFW = 4..6 MFMA groups per k-step): DMA instruction i of the eight goes to group i*NFW/8, the
+          // fragment reads of the next K-tile's first k-step to the first three groups
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            if ((i * NFW) / 8 == j) {
+              if (i < 4) la.issue(ra, ka, i, st, wave); else lb.issue(rb, kb, i - 4, st + G2_BOFF, wave);
+            }
+          if (j == 0) { G2_READ_A(0, a0); }
+          if (j == 1) { G2_READ_B(0, b0, 0, 2); }
+          if (j == 2) { G2_READ_B(0, b0, 2, NFW); }
+        }
         G2_MFMA_GROUP(j, a1, b1);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -503,12 +517,18 @@ double vita_gemm256_cost(const vita_gemm_desc& d, int* nf_out) {
   const int64_t tm = (d.m + G2_BM - 1) / G2_BM;
   const int kt_total = (int)((d.k + G2_BK - 1) / G2_BK);
   const int per = (kt_total + d.split_k - 1) / d.split_k, splits = (kt_total + per - 1) / per;
-  const int cand[3] = {13, 14, 16};
+  const int cand[6] = {13, 14, 16, 8, 10, 12};
+  // The 128..192-column tiles pay where a GEMM has the chip to itself and its 208..256-column grid ends in a thin last round
+  // (forward GEMMs with N = 1088 at M = 13826: proj 76 -> 66 us, fc2 171 -> 149 us).  The dgrad GEMMs (k-strided B) run
+  // beside the weight-gradient GEMMs of the second stream, which already fill such a round: there the narrow tiles
+  // measured +1.5 ms per step, so they are not candidates.
+  static const bool wide_only = getenv("VITA_GEMM_WIDE_ONLY") && getenv("VITA_GEMM_WIDE_ONLY")[0] == '1';
+  const int ncand = (wide_only || d.a_layout != 0 || d.b_layout != 0) ? 3 : 6;
   double best = 0; int best_nf = 0;
-  for (int c = 0; c < 3; ++c) {
+  for (int c = 0; c < ncand; ++c) {
     const int64_t tn = (d.n + cand[c] * 16 - 1) / (cand[c] * 16);
     const int64_t rounds = (tm * tn * splits + 255) / 256;
-    const double cost = (double)rounds * (cand[c] + 2.0) / splits;
+    const double cost = (double)rounds * (cand[c] + (cand[c] < 13 ? G2_NARROW_OVERHEAD : 2.0)) / splits;
     if (best_nf == 0 || cost < best) { best = cost; best_nf = cand[c]; }
   }
   if (nf_out) *nf_out = best_nf;
@@ -538,6 +558,9 @@ int vita_gemm256_launch(const vita_gemm_desc& d, int nf, hipStream_t s) {
   if (nf == 0) (void)vita_gemm256_cost(d, &nf);
 #define G2_CASE(LA, LB, AT)                                      \
   do {                                                           \
+    if (nf == 8) return g2_launch<LA, LB, 8, AT>(d, s);          \
+    if (nf == 10) return g2_launch<LA, LB, 10, AT>(d, s);        \
+    if (nf == 12) return g2_launch<LA, LB, 12, AT>(d, s);        \
     if (nf == 13) return g2_launch<LA, LB, 13, AT>(d, s);        \
     if (nf == 14) return g2_launch<LA, LB, 14, AT>(d, s);        \
     if (nf == 16) return g2_launch<LA, LB, 16, AT>(d, s);        \
