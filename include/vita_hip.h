@@ -175,7 +175,7 @@ int vita_softmax_bwd_rows(const void* p, int64_t ldp, const float* dp, int64_t l
  * qkv bf16 [B][N][3][H][hdp] (head dim zero-padded to hdp), o bf16 [B][N][H][hdp], lse fp32 [B][H][N].
  * vita_attn_supported(hd, hdp) != 0 tells whether a kernel is instantiated for that head size. */
 int vita_attn_supported(int64_t hd, int64_t hdp);
-/* ws (optional, 16-byte aligned, ws_bytes >= vita_attn_fwd_ws_bytes(hdp), a fixed ~0.3 MB * hdp): scratch in which
+/* ws (optional, 16-byte aligned, ws_bytes >= vita_attn_fwd_ws_bytes(hdp), a fixed ~0.66 MB * hdp): scratch in which
  * the workgroups of a partly filled last round, launched with their key sweep cut into ranges, leave fp32 partial
  * outputs that a combine kernel merges (fixed order); with ws == NULL the grid is launched whole. */
 int64_t vita_attn_fwd_ws_bytes(int64_t hdp);

@@ -1205,18 +1205,25 @@ static int att_num_cu() {
 }
 // These grids run one 8-wave workgroup per CU and every workgroup of a launch does the same work, so a grid of L
 // workgroups costs ceil(L / CUs) rounds.  When the last round is less than 3/4 full its `rem` workgroups are launched
-// separately with their sweep cut into nsplit ranges (rem * nsplit <= CUs, >= 8 tiles per range).
-static void att_tail_plan(int64_t L, int64_t ntiles, int ncu, int64_t* l_main, int* nsplit, int* tiles_per_split) {
+// separately with their sweep cut into nsplit ranges (>= 8 tiles per range, rem * nsplit <= slots partial results).  The
+// pieces may themselves take several rounds: the split that minimises ceil(rem * nsplit / CUs) / nsplit wins (142 left-over
+// workgroups of 721 tiles: 3 ranges = 426 pieces = 2 rounds of a third = 0.67 of a round instead of a whole one).
+static void att_tail_plan(int64_t L, int64_t ntiles, int ncu, int64_t slots, int64_t* l_main, int* nsplit, int* tiles_per_split) {
   *l_main = L; *nsplit = 1; *tiles_per_split = (int)ntiles;
   const int64_t rem = L % ncu;
   if (rem == 0 || rem * 4 > (int64_t)ncu * 3) return;
-  int64_t ns = ncu / rem;
-  if (ns > ntiles / 8) ns = ntiles / 8;
-  if (ns < 2) return;
-  const int64_t per = (ntiles + ns - 1) / ns;
-  *l_main = L - rem; *nsplit = (int)((ntiles + per - 1) / per); *tiles_per_split = (int)per;
+  double best = 0.95;                      // an unsplit tail costs one round; a split must save at least 5 % of it
+  int64_t best_per = 0;
+  for (int64_t ns = 2; ns <= ntiles / 8 && rem * ns <= slots; ++ns) {
+    const int64_t per = (ntiles + ns - 1) / ns, nse = (ntiles + per - 1) / per;
+    const double cost = (double)((rem * nse + ncu - 1) / ncu) * (double)per / (double)ntiles + 0.004 * (double)nse;
+    if (cost < best) { best = cost; best_per = per; }
+  }
+  if (best_per == 0) return;
+  *l_main = L - rem; *nsplit = (int)((ntiles + best_per - 1) / best_per); *tiles_per_split = (int)best_per;
 }
-static inline int64_t att_fwd_part_bytes(int64_t hdp) { return (int64_t)ATT_MAX_CU * 256 * (hdp + 1) * 4; }
+#define ATT_FWD_SLOTS 640      // partial outputs of the forward tail launch (256 query rows each)
+static inline int64_t att_fwd_part_bytes(int64_t hdp) { return (int64_t)ATT_FWD_SLOTS * 256 * (hdp + 1) * 4; }
 
 template <int HDP, int NKS>
 static int launch_fwd(const void* qkv, void* o, float* lse, void* ws, int64_t B, int64_t N, int64_t H, float scale, hipStream_t s) {
@@ -1233,7 +1240,7 @@ static int launch_fwd(const void* qkv, void* o, float* lse, void* ws, int64_t B,
   const int64_t L = B * H * ((N + NW * 32 - 1) / (NW * 32));
   const int ntiles = (int)((N + 31) / 32);
   int64_t l_main = L; int nsplit = 1, per = ntiles;
-  if (ws != nullptr && !no_tail) att_tail_plan(L, ntiles, att_num_cu(), &l_main, &nsplit, &per);
+  if (ws != nullptr && !no_tail) att_tail_plan(L, ntiles, att_num_cu(), ATT_FWD_SLOTS, &l_main, &nsplit, &per);
   const float c = scale * 1.4426950408889634f;
   if (l_main > 0)
     hipLaunchKernelGGL((attn_fwd_kernel<HDP, NKS, NW>), dim3((unsigned)l_main), dim3(NW * 64), lds, s, (const uint16_t*)qkv, (uint16_t*)o,
@@ -1291,7 +1298,7 @@ static int launch_bwd(const void* qkv, const void* o, const void* dout, const fl
     uint16_t* dsb = handoff ? (uint16_t*)((char*)ws + att_part_bytes(HDP)) : (uint16_t*)nullptr;
     const int64_t L = B * H * ((N + 127) / 128);
     int64_t l_main = L; int nsplit = 1, per = QT;
-    if (ws != nullptr && !no_tail) att_tail_plan(L, QT, att_num_cu(), &l_main, &nsplit, &per);
+    if (ws != nullptr && !no_tail) att_tail_plan(L, QT, att_num_cu(), ATT_MAX_CU, &l_main, &nsplit, &per);
     if (l_main > 0)
       hipLaunchKernelGGL((attn_bwd_dkdv8_kernel<HDP, NKS>), dim3((unsigned)l_main), dim3(512), lds_kv8, s, (const uint16_t*)qkv,
                          (const uint16_t*)dout, delta, (uint16_t*)dqkv, dsb, QT, KTP, (float*)nullptr, 0, 1, QT, (int)N, (int)H, scale);
