@@ -94,7 +94,7 @@ def cpu_baseline(frames, steps=2):
 
 # rocprofv3 kernel names behind each timed launch group of vita_amd.ops (for roofline.traffic)
 GROUP_KERNELS = {"attn_bwd_kernels": ("attn_delta_kernel", "attn_bwd_dkdv_kernel", "attn_bwd_dkdv8_kernel", "attn_bwd_dq_kernel",
-                                      "attn_bwd_dq_ds_kernel", "attn_bwd_tail_reduce_kernel"),
+                                      "attn_bwd_dq_ds_kernel", "attn_bwd_tail_reduce_kernel", "attn_bwd_dq_tail_reduce_kernel"),
                  "attn_fwd_kernel": ("attn_fwd_kernel",)}
 
 

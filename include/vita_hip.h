@@ -185,7 +185,7 @@ int vita_attn_fwd(const void* qkv, void* o, float* lse, void* ws, int64_t ws_byt
  * delta fp32 [B][H][2][N] scratch (written here: a copy of lse and rowsum(dout*o)); dqkv bf16 like qkv, every element of
  * the three parts is written (pads zero).
  * ws (optional, 16-byte aligned, ws_bytes >= vita_attn_bwd_ws_bytes(B, N, H, hdp) = B*H*N^2*2 B rounded up to
- * tiles + a fixed 0.23 MB * hdp): scratch through which the dK/dV kernel hands its bf16 dS tiles to a streaming dQ
+ * tiles + a fixed 0.66 MB * hdp): scratch through which the dK/dV kernel hands its bf16 dS tiles to a streaming dQ
  * kernel, so dQ costs one product instead of three, and in which the workgroups of a partly filled last round leave
  * fp32 partial dK/dV (summed in a fixed order); with ws == NULL the dQ kernel recomputes S and dP itself and the
  * dK/dV grid is launched whole (no extra memory). */

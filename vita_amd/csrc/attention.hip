@@ -1054,22 +1054,31 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const uint16_t* __r
 template <int HDP, int NKS, int NSLOT>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dq_ds_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ ds,
                                                                 uint16_t* __restrict__ dqkv, int QT, int KTP, int N, int H,
-                                                                float scale) {
+                                                                float scale, float* __restrict__ part, int wg_base, int nsplit,
+                                                                int tiles_per_split) {
   using C = AttCfg<HDP>;
   constexpr int RS = C::RS, NDT = C::NDT, TILE = C::TILE, BUF = TILE + 8 * 2048;   // ring slot = [ K image | 8 dS tiles ]
   constexpr int NI = 32 / C::RPI / 8, DPT = NI + 2;                                 // DMA instructions per wave per tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = blockIdx.y, b = blockIdx.z;
+  // 1-D grid over (batch, head, 256-query block) x nsplit key ranges.  nsplit > 1 only in the tail launch (the last, partly
+  // filled round of workgroups): a workgroup then sweeps key tiles [t0, t1) and leaves its fp32 partial dQ in `part`,
+  // summed in split order by attn_bwd_dq_tail_reduce_kernel.
+  const int QB = (N + 255) >> 8;
+  const int lin = nsplit == 1 ? (int)blockIdx.x : wg_base + (int)blockIdx.x / nsplit;
+  const int sp = (int)blockIdx.x % nsplit;
+  const int bx = lin % QB, h = (lin / QB) % H, b = lin / (QB * H);
   const int64_t ld = 3ll * H * HDP;
   const uint16_t* base = qkv + (int64_t)b * N * ld;
   const uint32_t extent = (uint32_t)((((int64_t)N - 1) * ld + HDP) * 2);
   const __amdgpu_buffer_rsrc_t rsK = mk_rsrc(base + (H + h) * HDP, extent);
   const uint32_t ds_bytes = (uint32_t)KTP * (uint32_t)QT * 2048u;
   const __amdgpu_buffer_rsrc_t rsDS = mk_rsrc(ds + ((int64_t)b * H + h) * KTP * QT * 1024, ds_bytes);
-  const int qt = blockIdx.x * 8 + wave;                 // this wave's query tile
+  const int qt = bx * 8 + wave;                         // this wave's query tile
   const bool qt_ok = qt < QT;                           // waves past the last tile read zeros
   const int ntiles = (N + 31) / 32;
+  const int t0 = sp * tiles_per_split;
+  const int t1 = t0 + tiles_per_split < ntiles ? t0 + tiles_per_split : ntiles;
 
   lds_zero<HDP>(smem, NSLOT * BUF, tid);
   f32x16 dq[NDT];
@@ -1093,14 +1102,14 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_ds_kernel(const uint16_t* 
   auto issue_piece = [&](int tile, int buf, int p) {
     char* bp = smem + buf * BUF;
     if (p < NI) {
-      const int tcl = tile < ntiles ? tile : ntiles;      // tiles past the end: every row out of range, reads zeros
+      const int tcl = tile < t1 ? tile : ntiles;          // tiles past the end: every row out of range, reads zeros
       offk.issue(rsK, (uint32_t)tcl * (uint32_t)(32 * ld * 2), bp, wave, p);
     } else {
       typedef __attribute__((address_space(3))) void lds_void;
       const int j = p - NI;
       const uint32_t toff = (uint32_t)tile * (uint32_t)QT * 2048u + j * 1024;     // past KTP: beyond the descriptor, zeros
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsDS, (lds_void*)(bp + TILE + wave * 2048 + j * 1024), 16,
-                                               qt_ok ? ds_voff + toff : 0xfffffff0u, 0, 0, 2);
+                                               qt_ok && tile < t1 ? ds_voff + toff : 0xfffffff0u, 0, 0, 2);
     }
   };
   auto issue = [&](int tile, int buf) {
@@ -1119,11 +1128,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_ds_kernel(const uint16_t* 
   };
   __syncthreads();
 #pragma unroll
-  for (int t = 0; t < NSLOT - 1; ++t) issue(t, t);
-  dma_wait_n<DPT>();               // tiles 0 .. NSLOT-3 have landed
+  for (int t = 0; t < NSLOT - 1; ++t) issue(t0 + t, t);
+  dma_wait_n<DPT>();               // tiles t0 .. t0 + NSLOT-3 have landed
   ring_barrier();
   int slot = 0;
-  for (int tile = 0; tile < ntiles; ++tile) {
+  for (int tile = t0; tile < t1; ++tile) {
     const int pre = slot >= 1 ? slot - 1 : NSLOT - 1;     // slot of tile t + NSLOT - 1 = slot of tile t - 1
     const bf16x8 b0 = ds_frag(std::integral_constant<int, 0>{}), b1 = ds_frag(std::integral_constant<int, 1>{});
     bf16x8 fr[3][2];
@@ -1156,8 +1165,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_ds_kernel(const uint16_t* 
   }
   dma_wait();      // prefetches past the last tile
   const int lq = lane & 31, hh = lane >> 5;
-  const int q = qt * 32 + 8 * ((lq >> 2) & 3) + 4 * (lq >> 4) + (lq & 3);
-  if (qt_ok && q < N) {
+  const int ql = 8 * ((lq >> 2) & 3) + 4 * (lq >> 4) + (lq & 3);
+  const int q = qt * 32 + ql;
+  if (part != nullptr) {
+    // part[(tail workgroup * nsplit + split)][256 queries][HDP] fp32, unscaled
+    if (qt_ok && q < N) {
+      float* prow = part + (((int64_t)(lin - wg_base) * nsplit + sp) * 256 + wave * 32 + ql) * HDP;
+#pragma unroll
+      for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+          *reinterpret_cast<f32x4*>(prow + i * 32 + 8 * rr + 4 * hh) =
+              f32x4{dq[i][4 * rr], dq[i][4 * rr + 1], dq[i][4 * rr + 2], dq[i][4 * rr + 3]};
+    }
+  } else if (qt_ok && q < N) {
     uint16_t* qrow = dqkv + ((int64_t)b * N + q) * ld + h * HDP;
 #pragma unroll
     for (int i = 0; i < NDT; ++i)
@@ -1170,6 +1191,25 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_ds_kernel(const uint16_t* 
   }
 }
 
+// dQ of the tail workgroups: sum the nsplit fp32 partials in split order (deterministic), scale, write bf16
+__global__ __launch_bounds__(256) void attn_bwd_dq_tail_reduce_kernel(const float* __restrict__ part, uint16_t* __restrict__ dqkv,
+                                                                      int wg_base, int nwg, int nsplit, int N, int H, int HDP,
+                                                                      float scale) {
+  const int c4 = HDP / 4;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)nwg * 256 * c4) return;
+  const int c = (int)(idx % c4), ql = (int)((idx / c4) % 256), w = (int)(idx / ((int64_t)c4 * 256));
+  const int QB = (N + 255) >> 8, lin = wg_base + w;
+  const int bx = lin % QB, h = (lin / QB) % H, b = lin / (QB * H);
+  const int q = bx * 256 + ql;
+  if (q >= N) return;
+  f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < nsplit; ++s)
+    a += *reinterpret_cast<const f32x4*>(part + (((int64_t)w * nsplit + s) * 256 + ql) * HDP + c * 4);
+  uint16_t* row = dqkv + ((int64_t)b * N + q) * (3ll * H * HDP) + h * HDP + c * 4;
+  *reinterpret_cast<u32x2*>(row) = u32x2{pack_bf16x2(a[0] * scale, a[1] * scale), pack_bf16x2(a[2] * scale, a[3] * scale)};
+}
+
 // Explicit instantiations: with the generic-lambda / if-constexpr bodies above hipcc (ROCm 7.2) silently skips the
 // host-side implicit instantiation of attn_bwd_dq_kernel from launch_bwd (undefined kernel handle at load time).
 #define ATT_INSTANTIATE_BWD(A, K)                                                                                      \
@@ -1178,7 +1218,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_ds_kernel(const uint16_t* 
   template __global__ void attn_bwd_dkdv8_kernel<A, K>(const uint16_t*, const uint16_t*, const float*, uint16_t*, uint16_t*, \
                                                        int, int, float*, int, int, int, int, int, float);            \
   template __global__ void attn_bwd_dq_ds_kernel<A, K, ATT_DQDS_NSLOT>(const uint16_t*, const uint16_t*, uint16_t*, int,   \
-                                                                       int, int, int, float);                        \
+                                                                       int, int, int, float, float*, int, int, int); \
   template __global__ void attn_bwd_dq_kernel<A, K>(const uint16_t*, const uint16_t*, const float*, const float*,    \
                                                     uint16_t*, int, int, float);
 template __global__ void attn_fwd_kernel<224, 13, 8>(const uint16_t*, uint16_t*, float*, float*, int, int, int, int, int, float);
@@ -1261,7 +1301,8 @@ static int launch_fwd(const void* qkv, void* o, float* lse, void* ws, int64_t B,
 static inline int64_t att_qt(int64_t N) { return (N + 31) / 32; }
 static inline int64_t att_ktp(int64_t N) { return 4 * ((N + 127) / 128); }
 // workspace = [ fp32 partial dK/dV of the tail workgroups (fixed upper bound) | bf16 dS tiles ]
-static inline int64_t att_part_bytes(int64_t hdp) { return (int64_t)ATT_MAX_CU * 2 * 128 * hdp * 4; }
+#define ATT_BWD_SLOTS 640     // 256-row fp32 partials: dK + dV of a 128-key tail workgroup (<= ATT_MAX_CU of them), then dQ pieces
+static inline int64_t att_part_bytes(int64_t hdp) { return (int64_t)ATT_BWD_SLOTS * 256 * hdp * 4; }
 
 template <int HDP, int NKS>
 static int launch_bwd(const void* qkv, const void* o, const void* dout, const float* lse, float* delta, void* dqkv, void* ws,
@@ -1313,9 +1354,23 @@ static int launch_bwd(const void* qkv, const void* o, const void* dout, const fl
   }
   VITA_CHECK_LAUNCH("vita_attn_bwd(dkdv)");
   if (handoff) {
-    dim3 gq((unsigned)((N + 255) / 256), (unsigned)H, (unsigned)B);
-    hipLaunchKernelGGL((attn_bwd_dq_ds_kernel<HDP, NKS, ATT_DQDS_NSLOT>), gq, dim3(512), lds_qds, s, (const uint16_t*)qkv,
-                       (const uint16_t*)((char*)ws + att_part_bytes(HDP)), (uint16_t*)dqkv, QT, KTP, (int)N, (int)H, scale);
+    // same tail treatment as the other grids; the partial region is free again (the dK/dV partials were reduced above)
+    const int64_t L = B * H * ((N + 255) / 256);
+    const int ntl = (int)((N + 31) / 32);
+    int64_t l_main = L; int nsplit = 1, per = ntl;
+    if (!no_tail) att_tail_plan(L, ntl, att_num_cu(), ATT_BWD_SLOTS, &l_main, &nsplit, &per);
+    const uint16_t* dsb = (const uint16_t*)((char*)ws + att_part_bytes(HDP));
+    if (l_main > 0)
+      hipLaunchKernelGGL((attn_bwd_dq_ds_kernel<HDP, NKS, ATT_DQDS_NSLOT>), dim3((unsigned)l_main), dim3(512), lds_qds, s,
+                         (const uint16_t*)qkv, dsb, (uint16_t*)dqkv, QT, KTP, (int)N, (int)H, scale, (float*)nullptr, 0, 1, ntl);
+    if (l_main < L) {
+      const int nwg = (int)(L - l_main);
+      hipLaunchKernelGGL((attn_bwd_dq_ds_kernel<HDP, NKS, ATT_DQDS_NSLOT>), dim3((unsigned)(nwg * nsplit)), dim3(512), lds_qds, s,
+                         (const uint16_t*)qkv, dsb, (uint16_t*)dqkv, QT, KTP, (int)N, (int)H, scale, (float*)ws, (int)l_main, nsplit, per);
+      const int64_t nthr = (int64_t)nwg * 256 * (HDP / 4);
+      hipLaunchKernelGGL(attn_bwd_dq_tail_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (const float*)ws,
+                         (uint16_t*)dqkv, (int)l_main, nwg, nsplit, (int)N, (int)H, HDP, scale);
+    }
   } else {
     hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, NKS>), grid, dim3(256), lds_q, s, (const uint16_t*)qkv, (const uint16_t*)dout, lse, delta,
                        (uint16_t*)dqkv, (int)N, (int)H, scale);
