@@ -1301,7 +1301,7 @@ static int launch_fwd(const void* qkv, void* o, float* lse, void* ws, int64_t B,
 static inline int64_t att_qt(int64_t N) { return (N + 31) / 32; }
 static inline int64_t att_ktp(int64_t N) { return 4 * ((N + 127) / 128); }
 // workspace = [ fp32 partial dK/dV of the tail workgroups (fixed upper bound) | bf16 dS tiles ]
-#define ATT_BWD_SLOTS 640     // 256-row fp32 partials: dK + dV of a 128-key tail workgroup (<= ATT_MAX_CU of them), then dQ pieces
+#define ATT_BWD_SLOTS 640     // 256-row fp32 partials: dK + dV of a 128-key tail workgroup (a tail workgroup x query range), then dQ pieces
 static inline int64_t att_part_bytes(int64_t hdp) { return (int64_t)ATT_BWD_SLOTS * 256 * hdp * 4; }
 
 template <int HDP, int NKS>
@@ -1339,7 +1339,7 @@ static int launch_bwd(const void* qkv, const void* o, const void* dout, const fl
     uint16_t* dsb = handoff ? (uint16_t*)((char*)ws + att_part_bytes(HDP)) : (uint16_t*)nullptr;
     const int64_t L = B * H * ((N + 127) / 128);
     int64_t l_main = L; int nsplit = 1, per = QT;
-    if (ws != nullptr && !no_tail) att_tail_plan(L, QT, att_num_cu(), ATT_MAX_CU, &l_main, &nsplit, &per);
+    if (ws != nullptr && !no_tail) att_tail_plan(L, QT, att_num_cu(), ATT_BWD_SLOTS, &l_main, &nsplit, &per);
     if (l_main > 0)
       hipLaunchKernelGGL((attn_bwd_dkdv8_kernel<HDP, NKS>), dim3((unsigned)l_main), dim3(512), lds_kv8, s, (const uint16_t*)qkv,
                          (const uint16_t*)dout, delta, (uint16_t*)dqkv, dsb, QT, KTP, (float*)nullptr, 0, 1, QT, (int)N, (int)H, scale);
