@@ -31,6 +31,10 @@ extern "C" {
 #define VITA_ERR_LAUNCH (-3)
 
 int vita_version(void);
+/* One wave that holds a CU for `us` microseconds (<= 100 ms) on `stream`.  No counterpart in the reference: the host side
+ * launches two of them to test whether two HIP streams really run concurrently (streams mapped to one hardware queue
+ * serialise) before it puts the weight-gradient GEMMs of the Block backward on a second stream. */
+int vita_spin_us(int64_t us, void* stream);
 /* last HIP error string captured by a failed launch on this thread ("" if none) */
 const char* vita_last_error(void);
 

@@ -33,6 +33,7 @@ class GemmDesc(C.Structure):
 # name -> argtypes (restype int unless noted).  Mirrors include/vita_hip.h one to one.
 SIGNATURES = {
     "vita_version": [],
+    "vita_spin_us": [i64, vp],
     "vita_gemm_bf16": [C.POINTER(GemmDesc), vp],
     "vita_gemm_bf16_ex": [C.POINTER(GemmDesc), i32, vp],
     "vita_pack_weight_bf16": [vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, vp],

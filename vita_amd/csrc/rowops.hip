@@ -11,6 +11,20 @@ void vita_set_error(const char* what, hipError_t e) {
 extern "C" const char* vita_last_error(void) { return g_err; }
 extern "C" int vita_version(void) { return 100; }
 
+// One wave that keeps its CU busy for `us` microseconds of the constant 100 MHz wall clock (the loop ends on time, whatever
+// the core clock does).  vita_amd.nn uses two of them to find out whether two HIP streams run concurrently: streams that
+// HIP maps to one hardware queue serialise, and the second stream of the Block backward must not share the main stream's.
+__global__ void spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+extern "C" int vita_spin_us(int64_t us, void* stream) {
+  VITA_REQUIRE(us > 0 && us <= 100000);
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)(us * 100));
+  VITA_CHECK_LAUNCH("vita_spin_us");
+  return VITA_OK;
+}
+
 // ------------------------------------------------------------------------------------- LayerNorm
 #define LN_MAXV 8   // float4 per lane -> d <= 2048
 // R rows per wave: every row's loads are in flight before the first reduction (more bytes in flight per wave

@@ -18,7 +18,8 @@ from typing import Optional
 import torch
 from torch import nn
 
-from . import ops
+from . import _lib, ops
+from ._lib import check
 
 _SHADOW_EPOCH = 0
 DEFAULT_FLASH = True    # fused attention; the materialised path remains for unsupported head sizes and as a cross-check
@@ -198,6 +199,39 @@ WGRAD_SIDE_STREAM = os.environ.get("VITA_WGRAD_STREAM", "1") != "0"
 _SIDE_STREAMS = {}            # device index -> the second HIP stream of that device
 
 
+_STREAM_PROBE = {}            # device index -> (candidates tried, ms of the winning pair of 0.2 ms spins) for diagnostics
+
+
+def _concurrent_stream(idx, main, tries=12, spin_us=200):
+    """A stream whose kernels really run beside `main`'s.  HIP multiplexes its streams onto a few hardware queues
+    (GPU_MAX_HW_QUEUES, 4 by default) and two streams on one queue serialise: with RCCL's and the reducer's streams
+    created first, the next pool stream landed on the main stream's queue and the two-stream backward silently lost its
+    overlap (+2.5 ms per step).  So candidates are tested: a 0.2 ms one-wave spin on each of the two streams takes
+    0.2 ms when they overlap and 0.4 ms when they do not."""
+    cands = []
+    best = None
+    for _ in range(tries):
+        c = torch.cuda.Stream(device=idx)
+        if any(c == o for o in cands):
+            break                                   # the pool wrapped around
+        cands.append(c)
+        c.wait_stream(main)
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(main)
+        check(_lib.lib().vita_spin_us(spin_us, main.cuda_stream), "spin")
+        check(_lib.lib().vita_spin_us(spin_us, c.cuda_stream), "spin")
+        main.wait_stream(c)
+        e1.record(main)
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        if best is None or ms < best[1]:
+            best = (c, ms)
+        if ms < 1.5e-3 * spin_us:
+            break
+    _STREAM_PROBE[idx] = (len(cands), best[1])
+    return best[0]
+
+
 class _SideStream:
     """Weight / bias gradient launches of one Block backward on a second HIP stream.
 
@@ -216,10 +250,10 @@ class _SideStream:
             return
         global _DEFERRED_DONE
         idx = device.index if device.index is not None else torch.cuda.current_device()
+        self.main = torch.cuda.current_stream(idx)
         self.side = _SIDE_STREAMS.get(idx)
         if self.side is None:
-            self.side = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
-        self.main = torch.cuda.current_stream(idx)
+            self.side = _SIDE_STREAMS[idx] = _concurrent_stream(idx, self.main)
         self.prev = None          # Block backwards never nest; a list left behind by a failed backward is dropped
         _DEFERRED_DONE = []
 
