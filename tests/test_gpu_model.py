@@ -195,6 +195,32 @@ def test_block_reference_dims(N):
         assert rel(v.grad, leaves[k].grad) < 2e-2, k
 
 
+def test_side_stream_runs_beside_the_main_stream():
+    """The second stream of the Block backward is chosen by a concurrency probe (vita_amd.nn._concurrent_stream): HIP
+    streams that share a hardware queue serialise.  Even after many other streams were taken from the pool, two 0.5 ms
+    spins - one per stream - must take about 0.5 ms, not 1 ms."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from vita_amd import _lib, nn as vnn
+    taken = [torch.cuda.Stream() for _ in range(5)]          # what RCCL / a reducer would have created first
+    main = torch.cuda.current_stream()
+    side = vnn._concurrent_stream(torch.cuda.current_device(), main)
+    assert side != main
+    tried, ms = vnn._STREAM_PROBE[torch.cuda.current_device()]
+    assert ms < 0.3, (tried, ms)
+    side.wait_stream(main)
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(main)
+    assert _lib.lib().vita_spin_us(500, main.cuda_stream) == 0
+    assert _lib.lib().vita_spin_us(500, side.cuda_stream) == 0
+    main.wait_stream(side)
+    e1.record(main)
+    e1.synchronize()
+    assert 0.45 < e0.elapsed_time(e1) < 0.75, e0.elapsed_time(e1)
+    assert _lib.lib().vita_spin_us(0, main.cuda_stream) != 0     # argument check
+    del taken
+
+
 def test_block_backward_side_stream_matches_single_stream():
     """Weight / bias gradients launched on the second HIP stream (vita_amd.nn._SideStream) equal the single-stream
     ones, both returned through autograd and accumulated in place into an existing fp32 .grad (split-K atomics:
