@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import math
 import os
+import weakref
 from typing import Optional
 
 import torch
@@ -44,10 +45,22 @@ class Dims:
 
 
 class _Shadows:
-    """bf16 padded copies of fp32 parameters, keyed by (version, epoch, data_ptr)."""
+    """bf16 padded copies of fp32 parameters, keyed by (version, epoch, data_ptr).
+
+    After an optimizer step every copy is stale.  Left alone they are rebuilt one by one when the forward first asks for
+    them - ~75 small HBM-bound launches on the main stream's critical path (0.76 ms per Stage-I step).  prefetch_shadows()
+    (called by FlatAdam.step) rebuilds the copies of every live holder on the second stream instead, in creation (=
+    forward) order with one event per holder, and get() makes the consumer's stream wait for its holder's event only: the
+    copies of later blocks are made beside the MFMA-bound kernels of the earlier ones."""
+
+    _live = weakref.WeakSet()
 
     def __init__(self):
         self._c = {}
+        self._build = {}          # name -> (param, build): what prefetch re-runs
+        self._ready = None        # event of a prefetch no consumer has waited for yet
+        _Shadows._live.add(self)
+        self._order = _Shadows._count = getattr(_Shadows, "_count", 0) + 1
 
     def get(self, name, param, build):
         key = (param._version, _SHADOW_EPOCH, param.data_ptr())
@@ -56,7 +69,49 @@ class _Shadows:
             with torch.no_grad():
                 hit = (key, build(param))
             self._c[name] = hit
+            self._build[name] = (weakref.ref(param), build)
+        elif self._ready is not None:
+            torch.cuda.current_stream(param.device).wait_event(self._ready)
+            self._ready = None
         return hit[1]
+
+    def refresh(self):
+        """Rebuild every known copy on the current stream; False when a parameter has gone."""
+        with torch.no_grad():
+            for name, (pref, build) in list(self._build.items()):
+                param = pref()
+                if param is None or not param.is_cuda:
+                    return False
+                key = (param._version, _SHADOW_EPOCH, param.data_ptr())
+                hit = self._c.get(name)
+                if hit is None or hit[0] != key:
+                    self._c[name] = (key, build(param))
+        return True
+
+
+SHADOW_PREFETCH = os.environ.get("VITA_SHADOW_PREFETCH", "1") != "0"
+
+
+def prefetch_shadows(device):
+    """Rebuild all stale bf16 copies on the second stream (see _Shadows); the caller has just changed the parameters on
+    the current stream of `device`."""
+    if not (SHADOW_PREFETCH and WGRAD_SIDE_STREAM) or device.type != "cuda":
+        return
+    holders = sorted((h for h in _Shadows._live if h._build), key=lambda h: h._order)
+    if not holders:
+        return
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    main = torch.cuda.current_stream(idx)
+    side = _SIDE_STREAMS.get(idx)
+    if side is None:
+        side = _SIDE_STREAMS[idx] = _concurrent_stream(idx, main)
+    side.wait_stream(main)          # after the optimizer step - and after every earlier use of the copies being replaced
+    with torch.cuda.stream(side):
+        for h in holders:
+            if h.refresh():
+                ev = torch.cuda.Event()
+                ev.record(side)
+                h._ready = ev
 
 
 def pad_tokens(x: torch.Tensor, Dp: int) -> torch.Tensor:

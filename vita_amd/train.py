@@ -14,7 +14,7 @@ from torch import nn
 from . import ops
 from .losses import CLIPLoss, recon_mse_from_logits
 from .networks import ImagingMaskedDecoder, ImagingMaskedEncoder, SimCLRProjectionHead, TabularViT
-from .nn import bump_shadow_epoch
+from .nn import bump_shadow_epoch, prefetch_shadows
 
 
 class ReconMAE(nn.Module):
@@ -111,6 +111,7 @@ class FlatAdam:
         ops.adam_step(self.p, self.g, self.m, self.v, self.lr if lr is None else lr, self.betas[0], self.betas[1],
                       self.eps, self.wd, grad_scale, self.t)
         bump_shadow_epoch()
+        prefetch_shadows(self.p.device)
 
 
 class BucketedAllReduce:
