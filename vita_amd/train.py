@@ -117,13 +117,16 @@ class FlatAdam:
 class BucketedAllReduce:
     """Gradient all-reduce over RCCL in ~bucket_mb buckets of the flat gradient buffer, launched from
     post-accumulate hooks as soon as every parameter of a bucket has its gradient (reverse order =
-    backward order), on a side stream so it overlaps the rest of backward."""
+    backward order).  The collective runs on the process group's own stream, ordered after what the
+    current stream holds at the launch, so it overlaps the rest of backward; no stream of our own in
+    between - HIP streams that share a hardware queue block one another at event waits, and such a
+    relay stream on the weight-gradient stream's queue cost that stream its overlap with the attention
+    kernels."""
 
     def __init__(self, opt: FlatAdam, group=None, bucket_mb=48):
         self.opt, self.group = opt, group
         self.world = dist.get_world_size(group)
         self.cuda = opt.g.is_cuda
-        self.stream = torch.cuda.Stream() if self.cuda else None
         cap = bucket_mb * (1 << 20) // 4
         self.buckets = []           # (start, end, n_params)
         self.bucket_of = {}
@@ -161,12 +164,7 @@ class BucketedAllReduce:
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
         self.launch_order.append(b)
-        if not self.cuda:      # gloo / CPU rehearsal of the same bucketing and hook logic
-            self.handles.append(dist.all_reduce(self.opt.g[lo:hi], group=self.group, async_op=True))
-            return
-        self.stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.stream):
-            self.handles.append(dist.all_reduce(self.opt.g[lo:hi], group=self.group, async_op=True))
+        self.handles.append(dist.all_reduce(self.opt.g[lo:hi], group=self.group, async_op=True))
 
     def finish(self):
         """Wait for every bucket (launching any whose hooks did not all fire) and reset."""
@@ -174,9 +172,7 @@ class BucketedAllReduce:
             if n != self.buckets[b][2]:
                 self._launch(b)
         for h in self.handles:
-            h.wait()
-        if self.cuda:
-            torch.cuda.current_stream().wait_stream(self.stream)
+            h.wait()                # CUDA: the current stream waits for the collective; gloo: the host does
         self.handles = []
         self.pending = [0] * len(self.buckets)
         self.fired = {}
