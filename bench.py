@@ -104,7 +104,7 @@ GROUP_KERNELS = {"attn_bwd_kernels": ("attn_delta_kernel", "attn_bwd_dkdv_kernel
 
 def pmc_traffic(group, frames, batch, launches_per_step):
     """HBM bytes per launch of a timed group from the newest committed PMC summary (profiles/*_traffic.json, written by
-    tools_profile_summary.py from separate FETCH_SIZE / WRITE_SIZE passes of this same command; FETCH_SIZE doubled as
+    tools/profile_summary.py from separate FETCH_SIZE / WRITE_SIZE passes of this same command; FETCH_SIZE doubled as
     the gfx950 guide prescribes).  None when no summary matches this workload."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):

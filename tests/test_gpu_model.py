@@ -285,6 +285,53 @@ def test_clip_loss_golden(golden):
         CLIPLoss(0.1, 1.5)
 
 
+def test_clip_global_negatives_fake_world(golden):
+    """The rank-local body of the cross-GPU CLIP loss (vita_amd.losses.clip_rank_forward / clip_rank_backward - exactly
+    what _ClipFn runs on each rank, Bg != Bl) executed serially for 8 ranks x 4 rows on the reference's own
+    concatenated-batch fixture (g5 glob_*: utils/clip_loss.py:27-40 on the 32-row batch): sum of the per-rank losses,
+    every rank's logits rows, labels, and direct + rank-summed cross gradients (the reduce-scatter, done here by
+    hand) against the reference values at 1e-4."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from vita_amd import ops
+    from vita_amd.losses import clip_rank_backward, clip_rank_forward
+    g = golden("g5_clip.npz")
+    world, Bl, tau, lam = 8, 4, 0.1, 0.5
+    A = torch.from_numpy(g["glob_a"]).cuda(); Bm = torch.from_numpy(g["glob_b"]).cuda()
+    a_all, ia_all = ops.l2_normalize_fwd(A.contiguous())
+    b_all, ib_all = ops.l2_normalize_fwd(Bm.contiguous())
+    loss = torch.zeros(1, device="cuda")
+    direct_a, direct_b, cross_sum = [], [], torch.zeros(2, world * Bl, 128, device="cuda")
+    logits_ref = torch.from_numpy(g["glob_logits"])
+    for r in range(world):
+        sl = slice(r * Bl, (r + 1) * Bl)
+        a, b = a_all[sl].contiguous(), b_all[sl].contiguous()
+        part, l_it, l_ti, d_it, d_ti, labels = clip_rank_forward(a, b, a_all, b_all, r, tau, lam)
+        loss += part
+        assert l_it.shape == (Bl, world * Bl)
+        assert torch.equal(labels.cpu(), r * Bl + torch.arange(Bl)) and labels.dtype == torch.int64
+        torch.testing.assert_close(l_it.cpu(), logits_ref[sl], rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(l_ti.cpu(), logits_ref.t()[sl], rtol=1e-4, atol=1e-5)
+        da, db, cross = clip_rank_backward(a, b, a_all, b_all, d_it, d_ti, tau)
+        assert cross.shape == (2, world * Bl, 128)
+        direct_a.append(da); direct_b.append(db)
+        cross_sum += cross
+    torch.testing.assert_close(loss[0].cpu(), torch.from_numpy(g["glob_loss"]), rtol=1e-4, atol=1e-6)
+    da_n = torch.cat(direct_a) + cross_sum[0]          # reduce-scatter: every rank receives the sum of its slice
+    db_n = torch.cat(direct_b) + cross_sum[1]
+    dA = ops.l2_normalize_bwd(da_n.contiguous(), a_all, ia_all)
+    dB = ops.l2_normalize_bwd(db_n.contiguous(), b_all, ib_all)
+    torch.testing.assert_close(dA.cpu(), torch.from_numpy(g["glob_da"]), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(dB.cpu(), torch.from_numpy(g["glob_db"]), rtol=1e-4, atol=1e-6)
+    # the single-rank autograd path over the same batch agrees too
+    from vita_amd.losses import CLIPLoss
+    a1 = A.clone().requires_grad_(True); b1 = Bm.clone().requires_grad_(True)
+    l1, lg1, _ = CLIPLoss(tau, lam)(a1, b1)
+    l1.backward()
+    torch.testing.assert_close(l1.cpu(), torch.from_numpy(g["glob_loss"]), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(a1.grad.cpu(), torch.from_numpy(g["glob_da"]), rtol=1e-4, atol=1e-6)
+
+
 # ----------------------------------------------------------------------------------------------- Stage II
 S2_IMG = (9, 5, 32, 32)                 # L = 9*1*4*4 = 144 tokens, mask 0.5 -> 72 kept
 S2_FEATS = {"numerical": [f"n{i}" for i in range(5)], "single_categorical": ["b0", "b1", "b2"],

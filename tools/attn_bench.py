@@ -1,8 +1,9 @@
 """Micro-benchmark of the attention kernels at bench shapes (development aid).
-usage: python tools_attn_bench.py [attn|ln|gemm|all] [handoff=0|1]"""
+usage: python tools/attn_bench.py [attn|ln|gemm|all] [handoff=0|1]"""
+import os
 import sys, time
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from vita_amd import ops
 
 def timeit(fn, n=5):

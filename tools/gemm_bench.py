@@ -1,7 +1,8 @@
 """GEMM micro-benchmark at the Stage-I shapes: old 128x128 kernel vs the 256-row LDS-DMA kernel (development aid)."""
+import os
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from vita_amd import ops
 
 

@@ -1,8 +1,9 @@
-"""One GEMM shape, one variant, N launches (for rocprofv3 --pmc passes).  usage: tools_gemm_one.py name M variant [n]"""
+"""One GEMM shape, one variant, N launches (for rocprofv3 --pmc passes).  usage: tools/gemm_one.py name M variant [n]"""
+import os
 import sys
 import torch
-sys.path.insert(0, ".")
-from tools_gemm_bench import run
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gemm_bench import run
 from vita_amd import ops
 name, M, v = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 shapes = {"qkv": (M, 3360, 1088, 0, 0, {}), "proj": (M, 1088, 1120, 0, 0, dict(out_f32=True, epi=ops.EPI_RESIDUAL)),

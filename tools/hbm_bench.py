@@ -1,9 +1,10 @@
 """HBM-bound kernels of the path at the Stage-I T=50 shapes (achieved GB/s for K1 / K3 / K4 and the
 loss / optimizer kernels).  Development aid; run on the GPU box.  Times are HIP-event times of the ops.* wrapper, so the
 output allocation (and the zero fill of the scatter target) is inside them."""
+import os
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from vita_amd import ops
 
 

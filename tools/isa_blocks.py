@@ -1,5 +1,5 @@
 """Per-basic-block instruction statistics of one kernel in a hipcc -S listing (development aid).
-usage: python tools_isa_blocks.py file.s mangled_kernel_name_substring"""
+usage: python tools/isa_blocks.py file.s mangled_kernel_name_substring"""
 import collections, re, sys
 s = open(sys.argv[1]).read()
 m = re.search(r'^(\S*' + re.escape(sys.argv[2]) + r'\S*):', s, re.M)

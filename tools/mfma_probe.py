@@ -1,11 +1,11 @@
-"""MFMA ceiling of the part, measured: register-only v_mfma_f32_32x32x16_bf16 loops (tools_mfma_probe.hip) at several grid
-sizes and waves per SIMD.  Build first (on the CPU box): python tools_mfma_probe.py build"""
+"""MFMA ceiling of the part, measured: register-only v_mfma_f32_32x32x16_bf16 loops (mfma_probe.hip) at several grid
+sizes and waves per SIMD.  Build first (on the CPU box): python mfma_probe.py build"""
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(ROOT, "tools_mfma_probe.so")
+SO = os.path.join(ROOT, "mfma_probe.so")
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC",
-                           os.path.join(ROOT, "tools_mfma_probe.hip"), "-o", SO])
+                           os.path.join(ROOT, "mfma_probe.hip"), "-o", SO])
     sys.exit(0)
 import torch
 lib = ctypes.CDLL(SO)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: bash tools_pmc.sh <tag> "<COUNTERS...>" <python script> [args]   (runs on the GPU box)
+# usage: bash tools/pmc.sh <tag> "<COUNTERS...>" <python script> [args]   (runs on the GPU box)
 # one --pmc pass with --kernel-trace; prints per-kernel average duration and per-launch counter sums
 TAG=$1; shift; CTRS=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$PWD}

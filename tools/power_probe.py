@@ -1,5 +1,6 @@
+import os
 import sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from vita_amd import ops
 def timeit(fn, n=5):
     fn(); torch.cuda.synchronize()

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): rocprofv3 kernel-trace stats + HBM traffic PMC passes of bench.py.
-# usage: bash tools_profile.sh <tag> [bench args...]
+# usage: bash tools/profile.sh <tag> [bench args...]
 set -e
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$PWD}

@@ -1,4 +1,4 @@
-"""Summarise a tools_profile.sh output directory into profiles/<tag>_*.{csv,md}."""
+"""Summarise a tools/profile.sh output directory into profiles/<tag>_*.{csv,md}."""
 import collections, csv, glob, json, os, sys
 src, tag = sys.argv[1], sys.argv[2]
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 4   # warmup + timed steps executed under the profiler

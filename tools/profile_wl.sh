@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box): bash tools_profile_wl.sh <tag> <bench args...>   kernel-trace stats only
+# usage (GPU box): bash tools/profile_wl.sh <tag> <bench args...>   kernel-trace stats only
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/$TAG

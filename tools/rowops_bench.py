@@ -1,7 +1,8 @@
 """LayerNorm / column-sum micro-benchmark at the Stage-I shapes (development aid; run on the GPU box)."""
+import os
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from vita_amd import ops
 
 

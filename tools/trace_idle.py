@@ -1,5 +1,5 @@
 """GPU busy / idle time and per-family wall-clock attribution of the last step in a rocprofv3 --kernel-trace CSV of bench.py
-(a step ends with adam_kernel).  usage: python tools_trace_idle.py <dir with *_kernel_trace.csv>"""
+(a step ends with adam_kernel).  usage: python tools/trace_idle.py <dir with *_kernel_trace.csv>"""
 import collections, csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*_kernel_trace.csv", recursive=True)[0]
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f)))

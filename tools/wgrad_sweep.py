@@ -1,10 +1,11 @@
 """Sweep (tile width, split-K) of the weight-gradient GEMMs at the model's shapes against nn._wgrad_plan's pick."""
+import os
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from vita_amd import ops
 from vita_amd.nn import _wgrad_plan
-from tools_gemm_bench import timeit
+from gemm_bench import timeit
 
 def sweep(name, m, n, k, row_seg=(0, 0), col_seg=(0, 0), rows_out=None, cols_out=None):
     rows_out = rows_out or m; cols_out = cols_out or n

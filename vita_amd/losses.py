@@ -43,11 +43,54 @@ def scatter_tower_grads(cross: torch.Tensor, group):
     return send[rank].contiguous()
 
 
+def clip_rank_forward(a, b, a_all, b_all, rank, tau, lam0):
+    """What ONE rank computes in the forward of the (global-negative) CLIP loss, given its own L2-normalised rows
+    a, b [Bl, d] and every rank's rows a_all, b_all [Bg, d] (rank r's rows at [r*Bl, (r+1)*Bl)):
+    the rank's rows of logits (image->tabular) and of logits.T (tabular->image), its share of the global-batch loss
+    (utils/clip_loss.py:33-38 with both CrossEntropy means taken over Bg) and d loss / d logits rows.
+    Returns (loss_part [1], l_it [Bl,Bg], l_ti [Bl,Bg], d_it, d_ti, labels = rank*Bl + arange(Bl))."""
+    Bl, d = a.shape
+    Bg, off = a_all.shape[0], rank * Bl
+    dev = a.device
+    l_it = torch.empty(Bl, Bg, dtype=torch.float32, device=dev)
+    l_ti = torch.empty(Bl, Bg, dtype=torch.float32, device=dev)
+    ops.sgemm(a, b_all, l_it, Bl, Bg, d, d, d, Bg, 0, 0, alpha=1.0 / tau)
+    ops.sgemm(b, a_all, l_ti, Bl, Bg, d, d, d, Bg, 0, 0, alpha=1.0 / tau)
+    loss = torch.zeros(1, dtype=torch.float32, device=dev)
+    d_it = torch.empty_like(l_it); d_ti = torch.empty_like(l_ti)
+    ops.ce_rows(l_it, Bg, Bl, Bg, off, lam0 / Bg, loss, dlogits=d_it)
+    ops.ce_rows(l_ti, Bg, Bl, Bg, off, (1.0 - lam0) / Bg, loss, dlogits=d_ti)
+    labels = off + torch.arange(Bl, device=dev)
+    return loss, l_it, l_ti, d_it, d_ti, labels
+
+
+def clip_rank_backward(a, b, a_all, b_all, d_it, d_ti, tau, cross_out=None):
+    """One rank's backward: (da, db) [Bl, d] = the terms through this rank's own rows of the two logit blocks, and
+    cross [2, Bg, d] = this rank's gradient with respect to EVERY rank's normalised embeddings through the gathered
+    operand (d a_all += d_ti^T b, d b_all += d_it^T a); the all-gather's backward sums cross over ranks and hands
+    each rank its slice.  With cross_out = (da, db) (single rank: Bg == Bl) the cross terms are added in place."""
+    Bl, d = a.shape
+    Bg = a_all.shape[0]
+    dev = a.device
+    da = torch.empty(Bl, d, dtype=torch.float32, device=dev)
+    db = torch.empty(Bl, d, dtype=torch.float32, device=dev)
+    ops.sgemm(d_it, b_all, da, Bl, d, Bg, Bg, d, d, 0, 1, alpha=1.0 / tau)
+    ops.sgemm(d_ti, a_all, db, Bl, d, Bg, Bg, d, d, 0, 1, alpha=1.0 / tau)
+    if cross_out is None:
+        cross = torch.empty(2, Bg, d, dtype=torch.float32, device=dev)
+        ops.sgemm(d_ti, b, cross[0], Bg, d, Bl, Bg, d, d, 1, 1, alpha=1.0 / tau)
+        ops.sgemm(d_it, a, cross[1], Bg, d, Bl, Bg, d, d, 1, 1, alpha=1.0 / tau)
+        return da, db, cross
+    assert Bg == Bl
+    ops.sgemm(d_ti, b, da, Bg, d, Bl, Bg, d, d, 1, 1, alpha=1.0 / tau, beta=1.0)
+    ops.sgemm(d_it, a, db, Bg, d, Bl, Bg, d, d, 1, 1, alpha=1.0 / tau, beta=1.0)
+    return da, db, None
+
+
 class _ClipFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, out0, out1, tau, lam0, group, grad_world_scale):
         out0 = out0.float().contiguous(); out1 = out1.float().contiguous()
-        Bl, d = out0.shape
         a, ia = ops.l2_normalize_fwd(out0)
         b, ib = ops.l2_normalize_fwd(out1)
         world, rank = (dist.get_world_size(group), dist.get_rank(group)) if group is not None else (1, 0)
@@ -55,43 +98,24 @@ class _ClipFn(torch.autograd.Function):
             a_all, b_all = gather_towers(a, b, group)
         else:
             a_all, b_all = a, b
-        Bg, off = world * Bl, rank * Bl
-        l_it = torch.empty(Bl, Bg, dtype=torch.float32, device=a.device)
-        l_ti = torch.empty(Bl, Bg, dtype=torch.float32, device=a.device)
-        ops.sgemm(a, b_all, l_it, Bl, Bg, d, d, d, Bg, 0, 0, alpha=1.0 / tau)
-        ops.sgemm(b, a_all, l_ti, Bl, Bg, d, d, d, Bg, 0, 0, alpha=1.0 / tau)
-        loss = torch.zeros(1, dtype=torch.float32, device=a.device)
-        d_it = torch.empty_like(l_it); d_ti = torch.empty_like(l_ti)
-        ops.ce_rows(l_it, Bg, Bl, Bg, off, lam0 / Bg, loss, dlogits=d_it)
-        ops.ce_rows(l_ti, Bg, Bl, Bg, off, (1.0 - lam0) / Bg, loss, dlogits=d_ti)
+        loss, l_it, _l_ti, d_it, d_ti, labels = clip_rank_forward(a, b, a_all, b_all, rank, tau, lam0)
         if world > 1:
             dist.all_reduce(loss, group=group)                           # report the global-batch loss
         ctx.save_for_backward(a, b, ia, ib, a_all, b_all, d_it, d_ti)
-        ctx.meta = (tau, group, world, Bl, Bg, d, grad_world_scale)
-        labels = off + torch.arange(Bl, device=a.device)
+        ctx.meta = (tau, group, world, grad_world_scale)
         ctx.mark_non_differentiable(l_it, labels)
         return loss[0], l_it, labels
 
     @staticmethod
     def backward(ctx, gloss, _gl, _glab):
         a, b, ia, ib, a_all, b_all, d_it, d_ti = ctx.saved_tensors
-        tau, group, world, Bl, Bg, d, gws = ctx.meta
-        dev = a.device
-        da = torch.empty(Bl, d, dtype=torch.float32, device=dev)
-        db = torch.empty(Bl, d, dtype=torch.float32, device=dev)
-        # direct terms: rows of this rank's logits
-        ops.sgemm(d_it, b_all, da, Bl, d, Bg, Bg, d, d, 0, 1, alpha=1.0 / tau)
-        ops.sgemm(d_ti, a_all, db, Bl, d, Bg, Bg, d, d, 0, 1, alpha=1.0 / tau)
-        # terms through the (gathered) other operand: d a_all += d_ti^T b ; d b_all += d_it^T a
+        tau, group, world, gws = ctx.meta
         if world > 1:
-            cross = torch.empty(2, Bg, d, dtype=torch.float32, device=dev)
-            ops.sgemm(d_ti, b, cross[0], Bg, d, Bl, Bg, d, d, 1, 1, alpha=1.0 / tau)
-            ops.sgemm(d_it, a, cross[1], Bg, d, Bl, Bg, d, d, 1, 1, alpha=1.0 / tau)
+            da, db, cross = clip_rank_backward(a, b, a_all, b_all, d_it, d_ti, tau)
             recv = scatter_tower_grads(cross, group)                      # backward of the all-gather
             da += recv[0]; db += recv[1]
         else:
-            ops.sgemm(d_ti, b, da, Bg, d, Bl, Bg, d, d, 1, 1, alpha=1.0 / tau, beta=1.0)
-            ops.sgemm(d_it, a, db, Bg, d, Bl, Bg, d, d, 1, 1, alpha=1.0 / tau, beta=1.0)
+            da, db, _ = clip_rank_backward(a, b, a_all, b_all, d_it, d_ti, tau, cross_out=True)
         g0 = ops.l2_normalize_bwd(da, a, ia)
         g1 = ops.l2_normalize_bwd(db, b, ib)
         s = gloss * gws
