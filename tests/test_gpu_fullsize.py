@@ -34,6 +34,9 @@ def test_masking_properties_full_length(ops):
     assert torch.equal(mk, (rs >= KEEP).float()) and int(mk.sum()) == 2 * (L - KEEP)
     # the stable rule is what torch's GPU sort does
     assert torch.equal(sh, torch.argsort(noise, dim=1, stable=True))
+    # ... and the reference's own call, torch.argsort(noise, dim=1) with the default stable=False
+    # (utils/imaging_model_related.py:272), gives the same order on the device
+    assert torch.equal(sh, torch.argsort(noise, dim=1))
 
 
 def test_gather_scatter_round_trip_full_size(ops):

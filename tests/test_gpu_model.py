@@ -163,10 +163,12 @@ def test_dropin_forward_and_checkpointing():
             assert rel(v.grad, g1[k]) < 1e-3, k
 
 
-@pytest.mark.parametrize("N", [197, 300])
-def test_block_reference_dims(N):
+@pytest.mark.parametrize("N,use_flash", [(197, True), (300, True), (197, False)])
+def test_block_reference_dims(N, use_flash):
     """One Block at the reference dims (D=1025, 5 heads of 205, hidden 4100), fwd + all grads.  600 tokens (N=300) are
-    enough for the weight gradients to take the large-tile split-K plan with the ragged 1025th row on its own launch."""
+    enough for the weight gradients to take the large-tile split-K plan with the ragged 1025th row on its own launch.
+    use_flash=False: the materialised-attention path (batched GEMMs + softmax rows), kept for head sizes without a
+    fused kernel, end to end through the same Block."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from vita_amd.nn import Block
@@ -180,6 +182,7 @@ def test_block_reference_dims(N):
             p[k] = torch.randn(p[k].shape, generator=g) * 0.05
     blk = Block(D, H, 4.0, qkv_bias=True).cuda()
     blk.load_state_dict(p, strict=True)
+    blk.use_flash = use_flash
     x = torch.randn(B, N, D)
     cot = torch.randn(B, N, D)
     xg = x.cuda().requires_grad_(True)

@@ -1233,15 +1233,19 @@ ATT_INSTANTIATE_BWD(128, 8)
 
 // ============================================================================================ host
 #define ATT_MAX_CU 320
+static bool att_env_flag(const char* name) {
+  const char* e = getenv(name);
+  return e && e[0] == '1';
+}
 static int att_num_cu() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
-      v = 256;
-    n = v > ATT_MAX_CU ? ATT_MAX_CU : v;
-  }
-  return n;
+  static int n[VITA_MAX_DEVICES];          // per device; written once under the per-device once flag
+  const int dev = vita_cur_device();
+  VITA_ONCE_PER_DEVICE({
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    n[dev] = v > ATT_MAX_CU ? ATT_MAX_CU : v;
+  });
+  return n[dev];
 }
 // These grids run one 8-wave workgroup per CU and every workgroup of a launch does the same work, so a grid of L
 // workgroups costs ceil(L / CUs) rounds.  When the last round is less than 3/4 full its `rem` workgroups are launched
@@ -1269,14 +1273,8 @@ template <int HDP, int NKS>
 static int launch_fwd(const void* qkv, void* o, float* lse, void* ws, int64_t B, int64_t N, int64_t H, float scale, hipStream_t s) {
   constexpr int NW = 8;
   const size_t lds = ATT_NSLOT * 2 * AttCfg<HDP>::TILE;
-  static bool attr = false;
-  static bool no_tail = false;    // VITA_ATTN_NO_TAIL_SPLIT=1: A/B switch of the tail launch
-  if (!attr) {
-    const char* e = getenv("VITA_ATTN_NO_TAIL_SPLIT");
-    no_tail = e && e[0] == '1';
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HDP, NKS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
+  static const bool no_tail = att_env_flag("VITA_ATTN_NO_TAIL_SPLIT");    // A/B switch of the tail launch
+  VITA_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HDP, NKS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t L = B * H * ((N + NW * 32 - 1) / (NW * 32));
   const int ntiles = (int)((N + 31) / 32);
   int64_t l_main = L; int nsplit = 1, per = ntiles;
@@ -1310,21 +1308,15 @@ static int launch_bwd(const void* qkv, const void* o, const void* dout, const fl
   const size_t lds_kv = ATT_BWD_NSLOT * (2 * AttCfg<HDP>::TILE + 256), lds_q = ATT_BWD_NSLOT * 2 * AttCfg<HDP>::TILE;
   const size_t lds_kv8 = ATT_BWD_NSLOT * (2 * AttCfg<HDP>::TILE + 256) + 4 * 2 * 2048;
   const size_t lds_qds = ATT_DQDS_NSLOT * (AttCfg<HDP>::TILE + 8 * 2048);
-  static bool attr = false;
-  static bool dkdv4 = false;      // VITA_ATTN_DKDV4=1: the one-wave-per-SIMD dK/dV kernel (kept for A/B measurements)
-  static bool no_tail = false;    // VITA_ATTN_NO_TAIL_SPLIT=1: A/B switch of the tail launch
-  if (!attr) {
-    const char* e = getenv("VITA_ATTN_DKDV4");
-    dkdv4 = e && e[0] == '1';
-    e = getenv("VITA_ATTN_NO_TAIL_SPLIT");
-    no_tail = e && e[0] == '1';
+  static const bool dkdv4 = att_env_flag("VITA_ATTN_DKDV4");                // the one-wave-per-SIMD dK/dV kernel (kept for A/B measurements)
+  static const bool no_tail = att_env_flag("VITA_ATTN_NO_TAIL_SPLIT");      // A/B switch of the tail launch
+  VITA_ONCE_PER_DEVICE({
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv8_kernel<HDP, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv8);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<HDP, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<HDP, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_ds_kernel<HDP, NKS, ATT_DQDS_NSLOT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_qds);
-    attr = true;
-  }
+  });
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((B * N + 3) / 4)), dim3(256), 0, s, (const uint16_t*)o, (const uint16_t*)dout,
                      lse, delta, B * N, (int)N, (int)H, HDP);
   VITA_CHECK_LAUNCH("vita_attn_bwd(delta)");

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include "../../include/vita_hip.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -76,6 +77,22 @@ __device__ __host__ __forceinline__ int64_t seg_map(int64_t i, int32_t seg_phys,
   const int64_t q = i / seg_phys, r = i % seg_phys;
   return r < seg_log ? q * seg_log + r : -1;
 }
+
+// Host-side set-up that must happen once per device and call site (hipFuncSetAttribute is per device): thread-safe, so
+// calls may arrive from the Python main thread and autograd's worker thread at once, and a process that drives several
+// GPUs sets the attribute on each of them.
+#define VITA_MAX_DEVICES 64
+static inline int vita_cur_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= VITA_MAX_DEVICES) d = 0;
+  return d;
+}
+struct VitaPerDeviceOnce { std::once_flag f[VITA_MAX_DEVICES]; };
+#define VITA_ONCE_PER_DEVICE(...)                                            \
+  do {                                                                       \
+    static VitaPerDeviceOnce once__;                                         \
+    std::call_once(once__.f[vita_cur_device()], [&]() { __VA_ARGS__; });     \
+  } while (0)
 
 void vita_set_error(const char* what, hipError_t e);
 #define VITA_CHECK_LAUNCH(name)                      \

@@ -310,11 +310,7 @@ extern "C" int vita_gemm_bf16_ex(const vita_gemm_desc* dp, int32_t variant, void
   hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(LA, LB)                                                                              \
   do {                                                                                              \
-    static bool attr_set_##LA##LB = false;                                                          \
-    if (!attr_set_##LA##LB) {                                                                       \
-      (void)hipFuncSetAttribute((const void*)gemm_kernel<LA, LB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      attr_set_##LA##LB = true;                                                                     \
-    }                                                                                               \
+    VITA_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm_kernel<LA, LB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL((gemm_kernel<LA, LB>), grid, dim3(NTHREADS), lds, s, P);                     \
   } while (0)
   if (d.a_layout == 0 && d.b_layout == 0) LAUNCH(0, 0);

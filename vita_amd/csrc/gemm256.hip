@@ -501,11 +501,7 @@ static int g2_launch(const vita_gemm_desc& d, hipStream_t s) {
   dim3 grid((unsigned)(P.tiles_m * P.tiles_n), (unsigned)splits, 1);
   constexpr size_t stage_bytes = 2 * G2_STAGE, epi_bytes = 8 * 32 * (((NF + 1) / 2) * 16 + 4) * 4;
   const size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm256_kernel<LA, LB, NF, ATOMIC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
+  VITA_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm256_kernel<LA, LB, NF, ATOMIC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((gemm256_kernel<LA, LB, NF, ATOMIC>), grid, dim3(G2_THREADS), lds, s, P);
   VITA_CHECK_LAUNCH("vita_gemm_bf16(256)");
   return VITA_OK;

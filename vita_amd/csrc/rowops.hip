@@ -342,8 +342,7 @@ extern "C" int vita_argsort_mask(const float* noise, int64_t n, int64_t l, int64
   VITA_REQUIRE(noise && ids_shuffle && ids_restore && mask);
   VITA_REQUIRE(n > 0 && n < 65536 && l > 0 && l <= 32768 && len_keep >= 0 && len_keep <= l);
   const size_t lds = (size_t)((l + 3) & ~3) * 4;
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)argsort_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072); attr = true; }
+  VITA_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)argsort_rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
   hipLaunchKernelGGL(argsort_rank_kernel, dim3((unsigned)((l + 255) / 256), (unsigned)n), dim3(ARGSORT_THREADS), lds, (hipStream_t)stream,
                      noise, (int)l, (int)len_keep, ids_shuffle, ids_restore, mask);
   VITA_CHECK_LAUNCH("vita_argsort_mask");

@@ -158,12 +158,21 @@ class _ReconMSEFn(torch.autograd.Function):
         B, L1, ldz = z.shape
         imgs = imgs.float().contiguous()
         L = L1 - 1
-        count = (mask.sum().item() if mask is not None else B * L) * P
         loss = torch.zeros(1, dtype=torch.float32, device=z.device)
         dz = torch.empty(B * L1, ldz, dtype=torch.bfloat16, device=z.device)
         pred = torch.empty(B, L, P, dtype=torch.float32, device=z.device) if want_pred else None
-        ops.sigmoid_mse_patch(z.contiguous(), ldz, imgs, patch, mask, 1.0 / count, loss, pred=pred, dz=dz, ld_dz=ldz)
-        ctx.save_for_backward(dz)
+        if mask is None:
+            inv = None
+            ops.sigmoid_mse_patch(z.contiguous(), ldz, imgs, patch, None, 1.0 / (B * L * P), loss, pred=pred, dz=dz, ld_dz=ldz)
+        else:
+            # mask_loss: mean over the masked rows only (utils/losses.py:118-121).  Their number stays on the device -
+            # no host sync in the middle of the forward; an all-kept mask gives 0/0 = NaN as the reference's mean of an
+            # empty selection does.
+            mask = mask.float().contiguous()
+            inv = 1.0 / (mask.sum() * P)
+            ops.sigmoid_mse_patch(z.contiguous(), ldz, imgs, patch, mask, 1.0, loss, pred=pred, dz=dz, ld_dz=ldz)
+            loss = loss * inv
+        ctx.save_for_backward(dz, inv)
         ctx.shape = (B, L1, ldz)
         if want_pred:
             ctx.mark_non_differentiable(pred)
@@ -172,7 +181,9 @@ class _ReconMSEFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gloss, _gp):
-        (dz,) = ctx.saved_tensors
+        dz, inv = ctx.saved_tensors
+        if inv is not None:
+            gloss = gloss * inv
         return (dz.float() * gloss).view(ctx.shape), None, None, None, None, None
 
 

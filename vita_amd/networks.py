@@ -110,14 +110,15 @@ class _TokenizeFn(torch.autograd.Function):
         dout = dout.contiguous().view(rows, Dp)
         if dyb is None:
             dyb = ops.cast_bf16(dout, Dp, rows, D, Dp)
-        dw = wgrad(dyb, Dp, cols, Pp, D, P, rows).reshape(wshape)
-        db = ops.colsum(dyb, Dp, rows, D) if has_b else None
+        need = ctx.needs_input_grad            # (img, w, b, cls, pos, ids, holder, dims, with_cls)
+        dw = wgrad(dyb, Dp, cols, Pp, D, P, rows).reshape(wshape) if need[1] else None
+        db = ops.colsum(dyb, Dp, rows, D) if (has_b and need[2]) else None
         dcls = None
         if with_cls:
-            dcls = ops.colsum(dout, (n + 1) * Dp, B, D)          # sum over batch of row 0
-            if has_b:
+            if need[3]:
+                dcls = ops.colsum(dout, (n + 1) * Dp, B, D).view(1, 1, D)      # sum over batch of row 0
+            if db is not None:
                 db = db - ops.colsum(dyb, (n + 1) * Dp, B, D)   # the zero-patch cls rows carry no bias grad
-            dcls = dcls.view(1, 1, D)
         return None, dw, db, dcls, None, None, None, None, None
 
 

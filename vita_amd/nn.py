@@ -230,7 +230,7 @@ GRAD_READY = {}              # id(param) -> callable(param): what a post-accumul
 def grad_target(param):
     """The tensor a parameter gradient may be accumulated into directly (fp32 atomics of the split-K GEMM / colsum),
     instead of materialising it and letting autograd run `grad += it`; None when there is no such buffer."""
-    g = param.grad if (INPLACE_PARAM_GRADS and param is not None) else None
+    g = param.grad if (INPLACE_PARAM_GRADS and param is not None and param.requires_grad) else None
     if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != param.shape or not g.is_cuda:
         return None
     return g
@@ -363,15 +363,21 @@ def bgrad(dy, ld, rows, cols, param=None):
 def with_bf16_twin(g, gb):
     """Attach the bf16 copy a kernel wrote beside an fp32 gradient (LayerNorm backward emits both in one pass).  The
     next backward node gets the very tensor object its producer returned when the two are chained directly, and then
-    skips its own fp32 -> bf16 cast pass; anything in between (gradient accumulation, a checkpoint boundary) hands over
-    a different object without the attribute, and the consumer casts as before."""
-    g._vita_bf16 = gb
+    skips its own fp32 -> bf16 cast pass.  Anything in between either hands over a different object without the
+    attribute (a checkpoint boundary, an out-of-place accumulation) or changes the values of this one IN PLACE
+    (autograd's input buffer may add a second consumer's gradient with `add_` - a skip-connection latent that also feeds
+    a decoder): the tensor's version counter is recorded with the copy, and a copy whose version no longer matches is
+    ignored, so the consumer casts the accumulated fp32 values as before."""
+    g._vita_bf16 = (gb, g._version)
     return g
 
 
 def bf16_twin(g, rows, ld):
-    gb = getattr(g, "_vita_bf16", None)
-    if gb is None or not g.is_contiguous() or tuple(gb.shape) != (rows, ld) or gb.device != g.device:
+    twin = getattr(g, "_vita_bf16", None)
+    if twin is None:
+        return None
+    gb, version = twin
+    if g._version != version or not g.is_contiguous() or tuple(gb.shape) != (rows, ld) or gb.device != g.device:
         return None
     return gb
 
@@ -402,8 +408,10 @@ class _BlockFn(torch.autograd.Function):
                  aux_in=x1, ld_aux=Dp, flops=2.0 * M * dm.D * dm.hidden)
         ctx.blk = blk
         ctx.shape = (B, N)
-        ctx.att_saved = att_saved
-        ctx.save_for_backward(x, mean1, rstd1, ln1, qkv, o, x1, mean2, rstd2, ln2, u, g, n1w, n2w)
+        # the attention's saved tensor (LSE, or the probabilities of the materialised path) goes through
+        # save_for_backward like the rest, so that activation checkpointing releases it with them
+        ctx.att_mode = att_saved[0]
+        ctx.save_for_backward(x, mean1, rstd1, ln1, qkv, o, x1, mean2, rstd2, ln2, u, g, n1w, n2w, att_saved[1])
         return x2.view(B, N, Dp)
 
     @staticmethod
@@ -412,22 +420,25 @@ class _BlockFn(torch.autograd.Function):
         dm: Dims = blk.dims
         B, N = ctx.shape
         M, Dp, D = B * N, dm.Dp, dm.D
-        x, mean1, rstd1, ln1, qkv, o, x1, mean2, rstd2, ln2, u, g, n1w, n2w = ctx.saved_tensors
+        x, mean1, rstd1, ln1, qkv, o, x1, mean2, rstd2, ln2, u, g, n1w, n2w, att_t = ctx.saved_tensors
         sh = blk.shadows()
         dyb = bf16_twin(dx2, M, Dp)
         dx2 = dx2.contiguous().view(M, Dp)
         if dyb is None:
             dyb = ops.cast_bf16(dx2, Dp, M, D, Dp)
         side = _SideStream(x.device)
+        # forward argument order: xp, blk, n1w, n1b, qkvw, qkvb, projw, projb, n2w, n2b, fc1w, fc1b, fc2w, fc2b.  A frozen
+        # parameter (load_pretrained_weights(freeze_encoder=True)) gets no weight / bias gradient launch at all.
+        need = ctx.needs_input_grad
         # ---- MLP (weight / bias gradients beside the dgrad chain, see _SideStream)
         a, mlp = blk.attn, blk.mlp
-        d_fc2w = side(wgrad, dyb, Dp, g, dm.Hp, D, dm.hidden, M, param=mlp.fc2.weight)
-        d_fc2b = side(bgrad, dyb, Dp, M, D, param=mlp.fc2.bias)
+        d_fc2w = side(wgrad, dyb, Dp, g, dm.Hp, D, dm.hidden, M, param=mlp.fc2.weight) if need[12] else None
+        d_fc2b = side(bgrad, dyb, Dp, M, D, param=mlp.fc2.bias) if need[13] else None
         du = torch.empty(M, dm.Hp, dtype=torch.bfloat16, device=x.device)   # GELU'(pre-activation), saved for backward
         ops.gemm(dyb, sh["fc2_w"], du, M, dm.Hp, Dp, Dp, dm.Hp, dm.Hp, b_layout=1, epilogue=ops.EPI_GELU_BWD, aux_in=u,
                  ld_aux=dm.Hp, flops=2.0 * M * D * dm.hidden)
-        d_fc1w = side(wgrad, du, dm.Hp, ln2, Dp, dm.hidden, D, M, param=mlp.fc1.weight)
-        d_fc1b = side(bgrad, du, dm.Hp, M, dm.hidden, param=mlp.fc1.bias)
+        d_fc1w = side(wgrad, du, dm.Hp, ln2, Dp, dm.hidden, D, M, param=mlp.fc1.weight) if need[10] else None
+        d_fc1b = side(bgrad, du, dm.Hp, M, dm.hidden, param=mlp.fc1.bias) if need[11] else None
         dln2 = torch.empty(M, Dp, dtype=torch.bfloat16, device=x.device)
         ops.gemm(du, sh["fc1_w"], dln2, M, Dp, dm.Hp, dm.Hp, Dp, Dp, b_layout=1, flops=2.0 * M * D * dm.hidden)
         if not side.on:
@@ -435,14 +446,16 @@ class _BlockFn(torch.autograd.Function):
         dx1, dx1b, d_n2w, d_n2b = ops.layernorm_bwd(dln2, Dp, x1, Dp, n2w, mean2, rstd2, M, D, Dp, dx_in=dx2,
                                                     want_bf16=True, ld_dxb=Dp)
         # ---- attention
-        d_projw = side(wgrad, dx1b, Dp, o, dm.AO, D, D, M, col_seg=(dm.hdp, dm.hd), n_phys=dm.AO, param=a.proj.weight)
-        d_projb = side(bgrad, dx1b, Dp, M, D, param=a.proj.bias)
+        d_projw = side(wgrad, dx1b, Dp, o, dm.AO, D, D, M, col_seg=(dm.hdp, dm.hd), n_phys=dm.AO, param=a.proj.weight) \
+            if need[6] else None
+        d_projb = side(bgrad, dx1b, Dp, M, D, param=a.proj.bias) if need[7] else None
         do = torch.empty(M, dm.AO, dtype=torch.bfloat16, device=x.device)
         ops.gemm(dx1b, sh["proj_w"], do, M, dm.AO, Dp, Dp, dm.AO, dm.AO, b_layout=1, flops=2.0 * M * D * D)
-        dqkv = attention_bwd(do, qkv, o, ctx.att_saved, B, N, dm)
-        d_qkvw = side(wgrad, dqkv, dm.QKV, ln1, Dp, 3 * D, D, M, row_seg=(dm.hdp, dm.hd), m_phys=dm.QKV, param=a.qkv.weight)
+        dqkv = attention_bwd(do, qkv, o, (ctx.att_mode, att_t), B, N, dm)
+        d_qkvw = side(wgrad, dqkv, dm.QKV, ln1, Dp, 3 * D, D, M, row_seg=(dm.hdp, dm.hd), m_phys=dm.QKV, param=a.qkv.weight) \
+            if need[4] else None
         d_qkvb = None
-        if blk.attn.qkv.bias is not None:
+        if blk.attn.qkv.bias is not None and need[5]:
             d_qkvb = side(lambda: ops.unpack_vec(ops.colsum(dqkv, dm.QKV, M, dm.QKV), 3 * D, seg=(dm.hdp, dm.hd)))
         dln1 = torch.empty(M, Dp, dtype=torch.bfloat16, device=x.device)
         ops.gemm(dqkv, sh["qkv_w"], dln1, M, Dp, dm.QKV, dm.QKV, Dp, Dp, b_layout=1, flops=6.0 * M * D * D)
@@ -511,6 +524,10 @@ class Block(nn.Module):
 def _require_cuda(x):
     if not x.is_cuda:
         raise RuntimeError("vita_amd modules run only on an MI355X (cuda device); there is no CPU fallback")
+    if x.device.index != torch.cuda.current_device():
+        # launches go to the CURRENT device's current stream (ops._s): one process per GPU, or set the device first
+        raise RuntimeError(f"vita_amd: tensor on cuda:{x.device.index} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "call torch.cuda.set_device() (one process per GPU)")
 
 
 # ----------------------------------------------------------------------------- LayerNorm / Linear on the padded stream
@@ -562,11 +579,15 @@ class _LinearFn(torch.autograd.Function):
         M = B * N
         dy = dy.contiguous().view(M, Np)
         dyb = ops.cast_bf16(dy, Np, M, out_f, Np)
-        dw = wgrad(dyb, Np, xb, Kp, out_f, in_f, M, param=ctx.lin_w)
-        db = bgrad(dyb, Np, M, out_f, param=ctx.lin_b)
-        dx = torch.empty(M, Kp, dtype=torch.float32, device=dy.device)
-        ops.gemm(dyb, ws, dx, M, Kp, Np, Np, Kp, Kp, b_layout=1, flops=2.0 * M * out_f * in_f)
-        return dx.view(B, N, Kp), dw, db, None, None
+        need = ctx.needs_input_grad            # (xp, w, b, holder, Np)
+        dw = wgrad(dyb, Np, xb, Kp, out_f, in_f, M, param=ctx.lin_w) if need[1] else None
+        db = bgrad(dyb, Np, M, out_f, param=ctx.lin_b) if need[2] else None
+        dx = None
+        if need[0]:
+            dx = torch.empty(M, Kp, dtype=torch.float32, device=dy.device)
+            ops.gemm(dyb, ws, dx, M, Kp, Np, Np, Kp, Kp, b_layout=1, flops=2.0 * M * out_f * in_f)
+            dx = dx.view(B, N, Kp)
+        return dx, dw, db, None, None
 
 
 def linear_padded(xp, lin: nn.Linear, holder: _Shadows, Np: int):

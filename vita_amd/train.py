@@ -82,7 +82,13 @@ class MultimodalSimCLR(nn.Module):
 
 
 class FlatAdam:
-    """torch.optim.Adam semantics on one flat fp32 buffer (params and grads become views of it)."""
+    """torch.optim.Adam semantics on one flat fp32 buffer (params and grads become views of it).
+
+    Restriction (differs from torch.optim.Adam, which skips a parameter whose .grad is None): the kernel runs over the
+    whole buffer every step, so a parameter that received no gradient still sees weight decay and moment decay, and
+    the step counter is shared.  Build the optimizer from the parameters that train (requires_grad is honoured at
+    construction) and do not freeze a parameter afterwards; every shipped Stage-I / Stage-II graph uses every
+    trainable parameter in every step."""
 
     def __init__(self, params, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.params = [p for p in params if p.requires_grad]
