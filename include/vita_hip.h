@@ -227,6 +227,44 @@ int vita_sigmoid_mse_patch(const float* z, int64_t ldz, const float* img, int64_
                            const float* mask, float inv_count, float* pred, float* loss, void* dz_bf16,
                            int64_t ld_dz, void* stream);
 
+/* ------------------------------------------------------------------ Stage-II glue
+ * TabularViT.forward_embeddings + cls + pos-embed (networks/tabular_encoders.py:80-93, 96-100) in one launch:
+ *   out[b][0]   = cls + pos[0]
+ *   out[b][1+f] = (n_class[f] == 0 ? x[b][f] * w_f + b_f : table_f[(long) x[b][f]]) + pos[1+f]
+ * x fp32 [B][F]; wptr / bptr int64 [F] (device memory): device addresses of the per-feature fp32 parameters
+ * (numerical_fe.i.weight [D][1] and .bias [D]; single_c_fe.i / multi_c_fe.i.weight [n_class][D], bptr 0);
+ * n_class int32 [F] (0 = numerical); cls fp32 [D]; pos fp32 [1+F][D] or NULL; out fp32 [B][1+F][ldo], pads zero.
+ * An index outside [0, n_class) is clamped (nn.Embedding would raise). */
+int vita_tabular_embed_fwd(const float* x, int64_t B, int64_t F, const int64_t* wptr, const int64_t* bptr,
+                           const int32_t* n_class, const float* cls, const float* pos, float* out, int64_t ldo,
+                           int64_t D, void* stream);
+/* backward: ADDS (one owner thread per element, fixed order, no atomics) the batch sums into the gradient tensors whose
+ * device addresses gw / gb hold (int64 [F], same shapes as the parameters, 0 = skip) and into dcls fp32 [D] (or NULL). */
+int vita_tabular_embed_bwd(const float* dout, int64_t ldo, const float* x, int64_t B, int64_t F, const int32_t* n_class,
+                           const int64_t* gw, const int64_t* gb, float* dcls, int64_t D, void* stream);
+/* y.mean(dim=1) over ALL tokens (models/MultimodalSimCLR.py:121,133): x fp32 [B][N][ld] (ld % 4 == 0, pads zero)
+ * -> out fp32 [B][D]; backward dx[b][n][:D] = dy[b] / N, pads zero. */
+int vita_token_mean_fwd(const float* x, int64_t ld, int64_t B, int64_t N, int64_t D, float* out, void* stream);
+int vita_token_mean_bwd(const float* dy, int64_t B, int64_t N, int64_t D, float* dx, int64_t ld, void* stream);
+/* nn.BatchNorm1d(D) of lightly's SimCLRProjectionHead (call sites models/MultimodalSimCLR.py:51-53,62-64), training mode:
+ * per-column batch mean / biased variance of x fp32 [B][D], y = (x - mean) * rstd * gamma + beta, then ReLU when relu != 0;
+ * mean / rstd fp32 [D] are saved for the backward; running_mean / running_var (optional) are updated in place with
+ * `momentum` and the unbiased variance, as torch does.  Local (per-rank) statistics: no SyncBN, like the reference. */
+int vita_batchnorm_fwd(const float* x, int64_t B, int64_t D, const float* gamma, const float* beta, float eps,
+                       int32_t relu, float* y, float* mean, float* rstd, float* running_mean, float* running_var,
+                       float momentum, void* stream);
+/* eval mode: running statistics instead of batch statistics */
+int vita_batchnorm_eval(const float* x, int64_t B, int64_t D, const float* gamma, const float* beta, float eps,
+                        int32_t relu, const float* running_mean, const float* running_var, float* y, void* stream);
+/* backward of vita_batchnorm_fwd; y is its output (the ReLU mask is y > 0).  dgamma / dbeta fp32 [D] are overwritten. */
+int vita_batchnorm_bwd(const float* dy, const float* x, const float* y, int64_t B, int64_t D, const float* gamma,
+                       const float* mean, const float* rstd, int32_t relu, float* dx, float* dgamma, float* dbeta,
+                       void* stream);
+/* out[r][c] += bias[c] on a dense fp32 [rows][D] (bias of a projection-head Linear after vita_sgemm_f32) */
+int vita_add_bias_rows(float* out, int64_t rows, int64_t D, const float* bias, void* stream);
+/* out[c] = sum_r x[r][c] of a dense fp32 [rows][D], any D (bias gradient of a projection-head Linear) */
+int vita_colsum_small_f32(const float* x, int64_t rows, int64_t D, float* out, void* stream);
+
 /* ------------------------------------------------------------------ optimizer
  * torch.optim.Adam step on a flat fp32 buffer (models/reconstruction_models.py:36-38;
  * coupled L2 weight decay for models/MultimodalSimCLR.py:92-99). */

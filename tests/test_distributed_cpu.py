@@ -142,3 +142,26 @@ def test_global_negative_clip_equals_concatenated_batch(golden):
     torch.testing.assert_close(total, torch.from_numpy(g["glob_loss"]), rtol=1e-5, atol=1e-6)
     ref, _, _ = O.clip_loss(a, b, tau, lam)
     torch.testing.assert_close(total, ref, rtol=1e-5, atol=1e-6)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset): the parent spawns the ranks before any GPU
+    call, rank 0's JSON line comes back through it, and a failing child makes the parent exit non-zero.  Rehearsed with
+    gloo and no GPU (VITA_BENCH_DRYRUN=1 swaps the timed region for the rendezvous + max-over-ranks plumbing)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["VITA_BENCH_DRYRUN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["max_over_ranks"] == 2.0 and out["steps"] == 3
+    # a rank that dies must surface as a non-zero exit of the parent, with no JSON line
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, VITA_BENCH_DRYRUN_FAIL_RANK="1"),
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -125,7 +125,7 @@ def test_stage1_step_vs_oracle():
     for k, gr in grads_ref.items():
         e = rel(named[k].grad, gr)
         worst = max(worst, e)
-        assert e < 3e-2, (k, e)
+        assert e < 2e-2, (k, e)
     # Adam-updated weights: each element moved by ~lr; compare the update direction
     for k in grads_ref:
         upd = named[k].detach().cpu() - p[k]
@@ -394,17 +394,111 @@ def test_tabular_vit_and_heads_vs_oracle():
     named = dict(model.named_parameters())
     for k, v in pr.items():
         if v.grad is not None and named[k].requires_grad:       # enc_pos_embed is frozen (tabular_encoders.py:33)
-            assert rel(named[k].grad, v.grad) < 3e-2, (k, rel(named[k].grad, v.grad))
-    # projection head (fp32 torch ops around BatchNorm batch statistics), forward and backward
-    h = yr.mean(1).detach()
-    hg = h.clone().cuda().requires_grad_(True)
-    z = model.projector_tabular(hg)
-    hr = h.clone().requires_grad_(True)
-    zr = O.projection_head(hr, p, "projector_tabular.")
-    assert rel(z, zr) < 1e-4
-    cz = torch.randn(8, 32, generator=torch.Generator().manual_seed(10))
-    (z * cz.cuda()).sum().backward(); (zr * cz).sum().backward()
-    assert rel(hg.grad, hr.grad) < 1e-3
+            assert rel(named[k].grad, v.grad) < 2e-2, (k, rel(named[k].grad, v.grad))
+    # the tokenisers alone are fp32: cls + 12 feature tokens + pos-embed against the oracle's first stage
+    emb = model.encoder_tabular.forward_embeddings(tabs.cuda())
+    # (the per-feature Linear(1, D) / Embedding lookups of networks/tabular_encoders.py:80-93, restated inline)
+    tok_ref = torch.cat([torch.cat([torch.nn.functional.linear(tabs[:, i:i + 1], p[f"encoder_tabular.numerical_fe.{i}.weight"],
+                                                                p[f"encoder_tabular.numerical_fe.{i}.bias"])[:, None] for i in range(5)], 1),
+                         torch.cat([p[f"encoder_tabular.single_c_fe.{i}.weight"][tabs[:, 5 + i].long()][:, None] for i in range(3)], 1),
+                         torch.cat([p[f"encoder_tabular.multi_c_fe.{i}.weight"][tabs[:, 8 + i].long()][:, None] for i in range(4)], 1)], 1)
+    assert emb.shape == tok_ref.shape == (8, 12, 129)
+    torch.testing.assert_close(emb.cpu(), tok_ref, rtol=1e-6, atol=1e-6)
+
+
+def test_projection_head_and_token_mean_native_fp32():
+    """SimCLRProjectionHead (sgemm + BatchNorm batch statistics + ReLU + sgemm) and the all-token mean on the native fp32
+    kernels against the oracle: forward, input gradient and every parameter gradient at 1e-4; BatchNorm running
+    statistics follow torch's update rule; eval mode uses them."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from vita_amd.networks import SimCLRProjectionHead, token_mean
+    g = torch.Generator().manual_seed(3)
+    for B, Din, Dout in ((8, 129, 32), (32, 1025, 128)):
+        head = SimCLRProjectionHead(Din, Din, Dout)
+        with torch.no_grad():
+            head.layers[1].weight.copy_(1 + 0.1 * torch.randn(Din, generator=g)); head.layers[1].bias.copy_(0.1 * torch.randn(Din, generator=g))
+        p = {"h.layers.0.weight": head.layers[0].weight.detach().clone(), "h.layers.1.weight": head.layers[1].weight.detach().clone(),
+             "h.layers.1.bias": head.layers[1].bias.detach().clone(), "h.layers.3.weight": head.layers[3].weight.detach().clone(),
+             "h.layers.3.bias": head.layers[3].bias.detach().clone()}
+        twin = torch.nn.Sequential(torch.nn.Linear(Din, Din, bias=False), torch.nn.BatchNorm1d(Din), torch.nn.ReLU(),
+                                   torch.nn.Linear(Din, Dout))
+        twin.load_state_dict(head.layers.state_dict())
+        head.cuda()
+        x = torch.randn(B, Din, generator=g)
+        cz = torch.randn(B, Dout, generator=g)
+        xg = x.clone().cuda().requires_grad_(True)
+        z = head(xg)
+        (z * cz.cuda()).sum().backward()
+        leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        xr = x.clone().requires_grad_(True)
+        zr = O.projection_head(xr, leaves, "h.")
+        (zr * cz).sum().backward()
+        assert rel(z, zr) < 1e-4 and rel(xg.grad, xr.grad) < 1e-4, (rel(z, zr), rel(xg.grad, xr.grad))
+        for k, v in head.layers.named_parameters():
+            assert rel(v.grad, leaves["h.layers." + k].grad) < 1e-4, (k, rel(v.grad, leaves["h.layers." + k].grad))
+        twin.train(); twin(x)
+        torch.testing.assert_close(head.layers[1].running_mean.cpu(), twin[1].running_mean, rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(head.layers[1].running_var.cpu(), twin[1].running_var, rtol=1e-4, atol=1e-6)
+        assert int(head.layers[1].num_batches_tracked) == 1
+        head.eval(); twin.eval()
+        with torch.no_grad():
+            assert rel(head(x.cuda()), twin(x)) < 1e-4
+    # mean over all tokens of a zero-padded [B, N, Dp] tensor, forward and backward
+    for B, N, D, Dp in ((3, 118, 129, 192), (2, 1153, 1025, 1088)):
+        xp = torch.zeros(B, N, Dp); xp[..., :D] = torch.randn(B, N, D, generator=g)
+        xg = xp.cuda().requires_grad_(True)
+        m = token_mean(xg, D)
+        cot = torch.randn(B, D, generator=g)
+        (m * cot.cuda()).sum().backward()
+        torch.testing.assert_close(m.cpu(), xp[..., :D].mean(1), rtol=1e-4, atol=1e-6)
+        ref = torch.zeros(B, N, Dp); ref[..., :D] = (cot / N)[:, None, :]
+        torch.testing.assert_close(xg.grad.cpu(), ref, rtol=1e-6, atol=0)
+
+
+def test_stage2_gradients_decomposed():
+    """Stage-II gradients at north_star's tolerances, without the BatchNorm / temperature amplification of the end-to-end
+    comparison: (1) heads + CLIP loss are fp32 - evaluated by the oracle at the tower outputs the GPU produced, loss,
+    head-parameter gradients and the cotangents of the token means agree at 1e-3; (2) each tower's parameter gradients
+    from the GPU's full backward equal the oracle tower's VJP of that cotangent at 2e-2 (bf16 tower)."""
+    model, p = _s2_build()
+    imgs, tabs = _s2_batch()
+    noise = draw_noise(21, 8, 144)
+    z_img, x_img, _ = model.forward_imaging(imgs.cuda())
+    z_tab, x_tab = model.forward_tabular(tabs.cuda())
+    x_img.retain_grad(); x_tab.retain_grad()
+    loss, _, _ = model.criterion(z_img, z_tab)
+    loss.backward()
+    named = dict(model.named_parameters())
+    # (1) heads + loss at the GPU's token means
+    hp = {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith("projector_")}
+    xi = x_img.detach().cpu().clone().requires_grad_(True); xt = x_tab.detach().cpu().clone().requires_grad_(True)
+    lref, _, _ = O.clip_loss(O.projection_head(xi, hp, "projector_imaging."), O.projection_head(xt, hp, "projector_tabular."), 0.1, 0.5)
+    lref.backward()
+    assert abs(loss.item() - lref.item()) < 1e-4 * abs(lref.item())
+    assert rel(x_img.grad, xi.grad) < 1e-3 and rel(x_tab.grad, xt.grad) < 1e-3, (rel(x_img.grad, xi.grad), rel(x_tab.grad, xt.grad))
+    gmax = max(v.grad.norm().item() for v in hp.values() if v.grad is not None)
+    for k, v in hp.items():
+        if v.grad is None:
+            continue
+        if v.grad.norm().item() < 1e-3 * gmax:
+            assert (named[k].grad.cpu() - v.grad).norm().item() < 1e-5 * gmax, k
+        else:
+            assert rel(named[k].grad, v.grad) < 1e-3, (k, rel(named[k].grad, v.grad))
+    # (2) towers: VJP of the same cotangent through the fp32 oracle towers
+    tp = {k: v.clone().requires_grad_(not k.endswith(O.FROZEN_KEYS)) for k, v in p.items() if k.startswith("encoder_")}
+    y, _, _ = O.encoder_forward(imgs, tp, patch_size=(5, 8, 8), num_heads=3, depth=2, mask_ratio=0.5, noise=noise,
+                                prefix="encoder_imaging.")
+    t = O.tabular_vit_forward(tabs, tp, prefix="encoder_tabular.", num_heads=3, depth=2, n_num=5, n_single=3, n_multi=4)
+    ((y.mean(1) * xi.grad).sum() + (t.mean(1) * xt.grad).sum()).backward()
+    assert rel(x_img, y.mean(1)) < 2e-2 and rel(x_tab, t.mean(1)) < 2e-2
+    worst = ("", 0.0)
+    for k, v in tp.items():
+        if v.grad is None:
+            continue
+        e = rel(named[k].grad, v.grad)
+        worst = max(worst, (k, e), key=lambda kv: kv[1])
+        assert e < 2e-2, (k, e)
 
 
 def test_stage2_step_vs_oracle():
@@ -420,10 +514,11 @@ def test_stage2_step_vs_oracle():
     assert logits.shape == (8, 8) and torch.equal(labels.cpu(), torch.arange(8))
     assert abs(loss.item() - loss_ref.item()) / loss_ref.item() < 2e-2
     named = dict(model.named_parameters())
-    # BatchNorm over 8 subjects followed by logits / 0.1 amplifies the towers' bf16 rounding about tenfold (the towers
-    # alone are held to 3e-2 above and in the Stage-I tests): per-tensor relative L2 within 0.15 and direction within
-    # cos > 0.99.  Tensors whose true gradient is zero (a bias in front of BatchNorm is cancelled by its mean
-    # subtraction) are held to an absolute bound instead.
+    # BatchNorm over 8 subjects followed by logits / 0.1 amplifies the towers' bf16 rounding about tenfold, so this
+    # end-to-end comparison is only a direction check (relative L2 within 0.15, cos > 0.99); the gradients are held to
+    # north_star's 2e-2 / 1e-3 by test_stage2_gradients_decomposed, which pins the cotangent between heads and towers.
+    # Tensors whose true gradient is zero (a bias in front of BatchNorm is cancelled by its mean subtraction) are held
+    # to an absolute bound instead.
     gmax = max(g.norm().item() for g in grads_ref.values())
     for k, gr in grads_ref.items():
         g = named[k].grad.detach().cpu()

@@ -105,6 +105,38 @@ def stage2():
             print(f"   {e:.4f} {k}")
 
 
+
+
+def small():
+    """Worst per-tensor errors of the small-dims tests (which tensor needs more than 2e-2, if any)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import test_gpu_model as T
+    from vita_amd.train import FlatAdam, stage1_train_step
+    model, p = T.build()
+    torch.manual_seed(3)
+    imgs = torch.rand(2, *T.IMG)
+    opt = FlatAdam(model.parameters(), lr=1e-4)
+    noise = T.draw_noise(55, 2, T.L_TOK)
+    stage1_train_step(model, opt, imgs.cuda())
+    for rnd in (False, True):
+        O.ROUND_BF16 = rnd
+        _, grads = O.stage1_train_step(imgs, {k: v.clone() for k, v in p.items()}, noise, {}, lr=1e-4, **T.ocfg())
+        O.ROUND_BF16 = False
+        named = dict(model.named_parameters())
+        errs = sorted(((rel(named[k].grad, g), k) for k, g in grads.items()), reverse=True)[:6]
+        print(f"small stage1 round={rnd}:", errs)
+    model, p = T._s2_build()
+    imgs, tabs = T._s2_batch()
+    y = model.encoder_tabular(tabs.cuda())
+    cot = torch.randn(8, 13, 129, generator=torch.Generator().manual_seed(9))
+    (y * cot.cuda()).sum().backward()
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith("encoder_tabular.")}
+    (O.tabular_vit_forward(tabs, pr, prefix="encoder_tabular.", num_heads=3, depth=2, n_num=5, n_single=3, n_multi=4) * cot).sum().backward()
+    named = dict(model.named_parameters())
+    errs = sorted(((rel(named[k].grad, v.grad), k) for k, v in pr.items() if v.grad is not None and named[k].requires_grad), reverse=True)[:6]
+    print("small tabular:", errs)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["stage1", "skip", "stage2"]
     for w in which:

@@ -62,6 +62,15 @@ SIGNATURES = {
     "vita_attn_fwd": [vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, f32, vp],
     "vita_attn_bwd_ws_bytes": [i64, i64, i64, i64],
     "vita_attn_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, f32, vp],
+    "vita_tabular_embed_fwd": [vp, i64, i64, vp, vp, vp, vp, vp, vp, i64, i64, vp],
+    "vita_tabular_embed_bwd": [vp, i64, vp, i64, i64, vp, vp, vp, vp, i64, vp],
+    "vita_token_mean_fwd": [vp, i64, i64, i64, i64, vp, vp],
+    "vita_token_mean_bwd": [vp, i64, i64, i64, vp, i64, vp],
+    "vita_batchnorm_fwd": [vp, i64, i64, vp, vp, f32, i32, vp, vp, vp, vp, vp, f32, vp],
+    "vita_batchnorm_eval": [vp, i64, i64, vp, vp, f32, i32, vp, vp, vp, vp],
+    "vita_batchnorm_bwd": [vp, vp, vp, i64, i64, vp, vp, vp, i32, vp, vp, vp, vp],
+    "vita_add_bias_rows": [vp, i64, i64, vp, vp],
+    "vita_colsum_small_f32": [vp, i64, i64, vp, vp],
     "vita_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, i64, vp],
     "vita_cine_partial_floats": [i64],
     "vita_cine_prepare": [vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, i64, i32, vp, vp, vp, vp],

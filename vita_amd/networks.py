@@ -19,10 +19,11 @@ from torch import nn
 from torch.utils.checkpoint import checkpoint
 
 from . import ops
-from .nn import Block, Dims, _Shadows, _require_cuda, bf16_twin, layer_norm_padded, linear_padded, pad_tokens, wgrad
+from .nn import (Block, Dims, _Shadows, _require_cuda, bf16_twin, grad_done, grad_target, layer_norm_padded, linear_padded,
+                 pad_tokens, wgrad)
 
 __all__ = ["PatchEmbed", "Masker", "sincos_pos_embed", "ImagingMaskedEncoder", "ViTDecoder", "ImagingMaskedDecoder",
-           "TabularViT", "SimCLRProjectionHead"]
+           "TabularViT", "SimCLRProjectionHead", "token_mean"]
 
 
 def _mark(t: torch.Tensor) -> torch.Tensor:
@@ -413,27 +414,39 @@ class TabularViT(nn.Module):
 
     _init_weights = ImagingMaskedEncoder._init_weights
 
+    def _feature_params(self):
+        """(weights, biases) in feature order numerical | single | multi; bias None for the embedding tables."""
+        ws = [l.weight for l in self.numerical_fe] + [t.weight for t in self.single_c_fe] + [t.weight for t in self.multi_c_fe]
+        bs = [l.bias for l in self.numerical_fe] + [None] * (self.num_single_c + self.num_multiple_c)
+        return ws, bs
+
+    def _tables(self, dev):
+        """Device tables of the per-feature parameter addresses (rebuilt only when a parameter moved, e.g. into
+        FlatAdam's flat buffer) and the class counts (0 = numerical)."""
+        ws, bs = self._feature_params()
+        key = (dev, tuple(w.data_ptr() for w in ws), tuple(b.data_ptr() if b is not None else 0 for b in bs))
+        if getattr(self, "_tab_key", None) != key:
+            self._tab_key = key
+            self._wptr = torch.tensor(key[1], dtype=torch.int64, device=dev)
+            self._bptr = torch.tensor(key[2], dtype=torch.int64, device=dev)
+            ncls = [0] * self.num_numerical + [t.num_embeddings for t in self.single_c_fe] + [t.num_embeddings for t in self.multi_c_fe]
+            self._ncls = torch.tensor(ncls, dtype=torch.int32, device=dev)
+        return self._wptr, self._bptr, self._ncls
+
     def forward_embeddings(self, x):
-        """(B, n_features) -> (B, n_features, D), feature order numerical | single | multi."""
-        nn_, ns = self.num_numerical, self.num_single_c
-        out = []
-        if nn_:
-            w = torch.stack([l.weight[:, 0] for l in self.numerical_fe])        # [n_num, D]
-            b = torch.stack([l.bias for l in self.numerical_fe])
-            out.append(x[:, :nn_, None] * w + b)
-        tables = list(self.single_c_fe) + list(self.multi_c_fe)
-        if tables:
-            sizes = torch.tensor([0] + [t.num_embeddings for t in tables[:-1]], device=x.device).cumsum(0)
-            idx = x[:, nn_:].to(torch.long) + sizes
-            out.append(torch.nn.functional.embedding(idx, torch.cat([t.weight for t in tables], dim=0)))
-        return torch.cat(out, dim=1)
+        """(B, n_features) -> (B, n_features, D), feature order numerical | single | multi (no cls, no pos-embed)."""
+        _require_cuda(x)
+        return self._embed_padded(x, with_pos=False)[:, 1:, :self.embedding_dim]
+
+    def _embed_padded(self, x, with_pos=True):
+        ws, bs = self._feature_params()
+        return _mark(_TabEmbedFn.apply(x.float().contiguous(), self, with_pos, self.cls_token, *ws,
+                                       *[b for b in bs if b is not None]))
 
     def forward_padded(self, x):
         _require_cuda(x)
-        D = self.embedding_dim
-        t = self.forward_embeddings(x.float())
-        t = torch.cat([self.cls_token.expand(t.shape[0], -1, -1), t], dim=1) + self.enc_pos_embed
-        xp = pad_tokens(t, ops.rup(D, 64))
+        # cls token + 117 per-feature tokenisers + pos-embed: one launch (vita_tabular_embed_fwd)
+        xp = self._embed_padded(x)
         for blk in self.network:
             if self.grad_checkpointing and torch.is_grad_enabled():
                 xp = checkpoint(blk.forward_padded, xp, use_reentrant=False)
@@ -447,12 +460,150 @@ class TabularViT(nn.Module):
         return self.forward_padded(x)[..., :self.embedding_dim]
 
 
+class _TabEmbedFn(torch.autograd.Function):
+    """cls + per-feature tokens (+ pos-embed) of TabularViT in one launch; the backward adds the batch sums straight
+    into the parameters' fp32 .grad buffers where they exist (FlatAdam's flat gradient), one launch for all 185
+    tensors, and reports them like every other in-place gradient."""
+
+    @staticmethod
+    def forward(ctx, x, mod, with_pos, cls, *params):
+        D = mod.embedding_dim
+        wptr, bptr, ncls = mod._tables(x.device)
+        pos = mod.enc_pos_embed.reshape(-1, D) if with_pos else None
+        out = ops.tabular_embed_fwd(x, wptr, bptr, ncls, cls.reshape(-1), pos, D, ops.rup(D, 64))
+        ctx.mod = mod
+        ctx.save_for_backward(x, ncls)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        mod = ctx.mod
+        x, ncls = ctx.saved_tensors
+        D = mod.embedding_dim
+        dev = x.device
+        dout = dout.contiguous()
+        ws, bs = mod._feature_params()
+        need = ctx.needs_input_grad                     # (x, mod, with_pos, cls, *weights, *biases)
+        nF = len(ws)
+        plist = [mod.cls_token] + ws + [b for b in bs if b is not None]
+        need_p = list(need[3:])
+        targets = [grad_target(p) if n else None for p, n in zip(plist, need_p)]
+        fresh_rows = sum(p.numel() // D for p, n, t in zip(plist, need_p, targets) if n and t is None)
+        fresh = torch.zeros(max(fresh_rows, 1), D, dtype=torch.float32, device=dev)
+        grads, addrs, row = [], [], 0
+        for p, n, t in zip(plist, need_p, targets):
+            if not n:
+                grads.append(None); addrs.append(0)
+            elif t is not None:
+                grads.append(None); addrs.append(t.data_ptr())
+            else:
+                r = p.numel() // D
+                g = fresh[row:row + r].view(p.shape); row += r
+                grads.append(g); addrs.append(g.data_ptr())
+        key = tuple(addrs)
+        cache = getattr(mod, "_grad_tables", None)
+        if cache is None or cache[0] != key:
+            gw = torch.tensor(addrs[1:1 + nF], dtype=torch.int64, device=dev)
+            it = iter(addrs[1 + nF:])
+            gb = torch.tensor([next(it) if b is not None else 0 for b in bs], dtype=torch.int64, device=dev)
+            cache = (key, gw, gb)
+            if fresh_rows == 0:
+                mod._grad_tables = cache              # stable addresses (the flat gradient buffer): keep the tables
+        _, gw, gb = cache
+        dcls = None
+        if addrs[0]:
+            dcls = targets[0].view(-1) if targets[0] is not None else grads[0].view(-1)
+        ops.tabular_embed_bwd(dout, dout.shape[-1], x, ncls, gw, gb, dcls, D)
+        for p, n, t in zip(plist, need_p, targets):
+            if n and t is not None:
+                grad_done(p)
+        return (None, None, None, *grads)
+
+
+class _TokenMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xp, D):
+        ctx.meta = (xp.shape, D)
+        return ops.token_mean_fwd(xp.contiguous(), D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (B, N, ld), D = ctx.meta
+        return ops.token_mean_bwd(dy.float().contiguous(), B, N, D, ld), None
+
+
+def token_mean(xp, D):
+    """y.mean(dim=1) over ALL tokens (models/MultimodalSimCLR.py:121,133) of a zero-padded [B, N, Dp] tensor -> [B, D]."""
+    return _TokenMeanFn.apply(xp, D)
+
+
+class _HeadFn(torch.autograd.Function):
+    """Linear(no bias) -> BatchNorm1d (batch statistics) -> ReLU -> Linear, all fp32 in libvita_hip.so
+    (vita_sgemm_f32, vita_batchnorm_fwd / _bwd): no rocBLAS / ATen GEMM on the Stage-II product path."""
+
+    @staticmethod
+    def forward(ctx, x, w0, gamma, beta, w3, b3, bn):
+        x = x.float().contiguous()
+        B, Din = x.shape
+        Hd, Dout = w0.shape[0], w3.shape[0]
+        dev = x.device
+        h = torch.empty(B, Hd, dtype=torch.float32, device=dev)
+        ops.sgemm(x, w0, h, B, Hd, Din, Din, Din, Hd)
+        if bn.training or bn.running_mean is None:
+            track = bn.training and bn.track_running_stats and bn.running_mean is not None
+            a, mean, rstd = ops.batchnorm_fwd(h, gamma, beta, bn.eps, True, bn.running_mean if track else None,
+                                              bn.running_var if track else None,
+                                              bn.momentum if bn.momentum is not None else 0.1)
+            if track and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+            ctx.train = True
+        else:
+            a = ops.batchnorm_eval(h, gamma, beta, bn.eps, True, bn.running_mean, bn.running_var)
+            mean = rstd = torch.empty(0, device=dev)
+            ctx.train = False
+        z = torch.empty(B, Dout, dtype=torch.float32, device=dev)
+        ops.sgemm(a, w3, z, B, Dout, Hd, Hd, Hd, Dout)
+        if b3 is not None:
+            ops.add_bias_rows(z, b3)
+        ctx.save_for_backward(x, w0, gamma, w3, h, a, mean, rstd)
+        ctx.has_b3 = b3 is not None
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        if not ctx.train:
+            raise NotImplementedError("vita_amd.SimCLRProjectionHead: backward in eval mode (running statistics) is not implemented")
+        x, w0, gamma, w3, h, a, mean, rstd = ctx.saved_tensors
+        dz = dz.float().contiguous()
+        B, Din = x.shape
+        Hd, Dout = w0.shape[0], w3.shape[0]
+        dev = x.device
+        need = ctx.needs_input_grad                     # (x, w0, gamma, beta, w3, b3, bn)
+        db3 = ops.colsum_small(dz) if (ctx.has_b3 and need[5]) else None
+        dw3 = None
+        if need[4]:
+            dw3 = torch.empty(Dout, Hd, dtype=torch.float32, device=dev)
+            ops.sgemm(dz, a, dw3, Dout, Hd, B, Dout, Hd, Hd, 1, 1)
+        da = torch.empty(B, Hd, dtype=torch.float32, device=dev)
+        ops.sgemm(dz, w3, da, B, Hd, Dout, Dout, Hd, Hd, 0, 1)
+        dh, dgamma, dbeta = ops.batchnorm_bwd(da, h, a, gamma, mean, rstd, True)
+        dw0 = None
+        if need[1]:
+            dw0 = torch.empty(Hd, Din, dtype=torch.float32, device=dev)
+            ops.sgemm(dh, x, dw0, Hd, Din, B, Hd, Din, Din, 1, 1)
+        dx = None
+        if need[0]:
+            dx = torch.empty(B, Din, dtype=torch.float32, device=dev)
+            ops.sgemm(dh, w0, dx, B, Din, Hd, Hd, Din, Din, 0, 1)
+        return dx, dw0, dgamma if need[2] else None, dbeta if need[3] else None, dw3, db3, None
+
+
 class SimCLRProjectionHead(nn.Module):
     """lightly's SimCLR projection head as the reference calls it (in, hidden, out): Linear(bias=False) ->
     BatchNorm1d -> ReLU -> Linear.  lightly is not pinned by the reference (absent from requirements.txt) and
     not installed here: the layout follows lightly's published SimCLR head and is an assumption.
-    A (B, D) x (D, D) GEMM at B = 32..256 is latency-sized; it stays on stock torch ops, BatchNorm with local
-    (per-rank) statistics as in the reference."""
+    Same sub-module / state_dict names (layers.0 / .1 / .3); the arithmetic runs in libvita_hip.so in fp32 (_HeadFn),
+    BatchNorm with local (per-rank) batch statistics as in the reference (no SyncBN)."""
 
     def __init__(self, input_dim: int = 2048, hidden_dim: int = 2048, output_dim: int = 128):
         super().__init__()
@@ -460,4 +611,6 @@ class SimCLRProjectionHead(nn.Module):
                                     nn.Linear(hidden_dim, output_dim, bias=True))
 
     def forward(self, x):
-        return self.layers(x)
+        _require_cuda(x)
+        l0, bn, _, l3 = self.layers
+        return _HeadFn.apply(x, l0.weight, bn.weight, bn.bias, l3.weight, l3.bias, bn)

@@ -238,6 +238,74 @@ def sigmoid_mse_patch(z, ldz, img, patch, mask, inv_count, loss, pred=None, dz=N
                                             _p(mask), inv_count, _p(pred), loss.data_ptr(), _p(dz), ld_dz, _s()), "sigmoid_mse_patch")
 
 
+def tabular_embed_fwd(x, wptr, bptr, n_class, cls, pos, D, ldo):
+    """x fp32 [B, F] -> fp32 [B, 1+F, ldo] (cls row, per-feature tokens, + pos-embed; pads zero)."""
+    B, F = x.shape
+    out = torch.empty(B, F + 1, ldo, dtype=torch.float32, device=x.device)
+    check(_lib.lib().vita_tabular_embed_fwd(x.data_ptr(), B, F, wptr.data_ptr(), bptr.data_ptr(), n_class.data_ptr(),
+                                            cls.data_ptr(), _p(pos), out.data_ptr(), ldo, D, _s()), "tabular_embed_fwd")
+    return out
+
+
+def tabular_embed_bwd(dout, ldo, x, n_class, gw, gb, dcls, D):
+    B, F = x.shape
+    check(_lib.lib().vita_tabular_embed_bwd(dout.data_ptr(), ldo, x.data_ptr(), B, F, n_class.data_ptr(), gw.data_ptr(),
+                                            gb.data_ptr(), _p(dcls), D, _s()), "tabular_embed_bwd")
+
+
+def token_mean_fwd(xp, D):
+    B, N, ld = xp.shape
+    out = torch.empty(B, D, dtype=torch.float32, device=xp.device)
+    check(_lib.lib().vita_token_mean_fwd(xp.data_ptr(), ld, B, N, D, out.data_ptr(), _s()), "token_mean_fwd")
+    return out
+
+
+def token_mean_bwd(dy, B, N, D, ld):
+    dx = torch.empty(B, N, ld, dtype=torch.float32, device=dy.device)
+    check(_lib.lib().vita_token_mean_bwd(dy.data_ptr(), B, N, D, dx.data_ptr(), ld, _s()), "token_mean_bwd")
+    return dx
+
+
+def batchnorm_fwd(x, gamma, beta, eps, relu, running_mean=None, running_var=None, momentum=0.1):
+    B, D = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(D, dtype=torch.float32, device=x.device); rstd = torch.empty_like(mean)
+    check(_lib.lib().vita_batchnorm_fwd(x.data_ptr(), B, D, _p(gamma), _p(beta), eps, int(relu), y.data_ptr(), mean.data_ptr(),
+                                        rstd.data_ptr(), _p(running_mean), _p(running_var), momentum, _s()), "batchnorm_fwd")
+    return y, mean, rstd
+
+
+def batchnorm_eval(x, gamma, beta, eps, relu, running_mean, running_var):
+    B, D = x.shape
+    y = torch.empty_like(x)
+    check(_lib.lib().vita_batchnorm_eval(x.data_ptr(), B, D, _p(gamma), _p(beta), eps, int(relu), running_mean.data_ptr(),
+                                         running_var.data_ptr(), y.data_ptr(), _s()), "batchnorm_eval")
+    return y
+
+
+def batchnorm_bwd(dy, x, y, gamma, mean, rstd, relu):
+    B, D = x.shape
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(D, dtype=torch.float32, device=x.device); dbeta = torch.empty_like(dgamma)
+    check(_lib.lib().vita_batchnorm_bwd(dy.data_ptr(), x.data_ptr(), y.data_ptr(), B, D, _p(gamma), mean.data_ptr(),
+                                        rstd.data_ptr(), int(relu), dx.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), _s()),
+          "batchnorm_bwd")
+    return dx, dgamma, dbeta
+
+
+def add_bias_rows(out, bias):
+    rows, D = out.shape
+    check(_lib.lib().vita_add_bias_rows(out.data_ptr(), rows, D, bias.data_ptr(), _s()), "add_bias_rows")
+    return out
+
+
+def colsum_small(x):
+    rows, D = x.shape
+    out = torch.empty(D, dtype=torch.float32, device=x.device)
+    check(_lib.lib().vita_colsum_small_f32(x.data_ptr(), rows, D, out.data_ptr(), _s()), "colsum_small")
+    return out
+
+
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, grad_scale, step):
     check(_lib.lib().vita_adam_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps,
                                     weight_decay, grad_scale, step, _s()), "adam_step")

@@ -13,7 +13,7 @@ from torch import nn
 
 from . import ops
 from .losses import CLIPLoss, recon_mse_from_logits
-from .networks import ImagingMaskedDecoder, ImagingMaskedEncoder, SimCLRProjectionHead, TabularViT
+from .networks import ImagingMaskedDecoder, ImagingMaskedEncoder, SimCLRProjectionHead, TabularViT, token_mean
 from .nn import bump_shadow_epoch, prefetch_shadows
 
 
@@ -65,13 +65,16 @@ class MultimodalSimCLR(nn.Module):
         self.criterion = CLIPLoss(temperature=temperature, lambda_0=lambda_0, gather_distributed=gather_distributed)
 
     def forward_imaging(self, x):
-        y, _, _ = self.encoder_imaging(x)
-        x_img = y.mean(dim=1) if self.avg_token else y[:, 0, :]
+        yp, _, _ = self.encoder_imaging.forward_padded(x)
+        D = self.encoder_imaging.enc_embed_dim
+        y = yp[..., :D]
+        x_img = token_mean(yp, D) if self.avg_token else y[:, 0, :].contiguous()
         return self.projector_imaging(x_img), x_img, y
 
     def forward_tabular(self, x):
-        y = self.encoder_tabular(x)
-        x_tab = y.mean(dim=1) if self.avg_token else y[:, 0, :]
+        yp = self.encoder_tabular.forward_padded(x)
+        D = self.encoder_tabular.embedding_dim
+        x_tab = token_mean(yp, D) if self.avg_token else yp[:, 0, :D].contiguous()
         return self.projector_tabular(x_tab), x_tab
 
     def training_loss(self, imgs, tabs):
