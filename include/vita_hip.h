@@ -14,7 +14,8 @@
  *   - return value: 0 = OK; VITA_ERR_* (negative) otherwise.  No C++ exception crosses.
  *   - bf16 buffers are raw uint16 storage; "ld" = leading dimension in ELEMENTS.
  *   - bf16 buffers and lds must be 16-byte aligned / multiples of 8 elements.
- *   - re-entrant: no global mutable state (calls arrive from the autograd worker thread too).
+ *   - re-entrant (calls arrive from the autograd worker thread too): the only process-global state is one-time
+ *     per-device set-up behind std::call_once, and the device array of vita_layernorm_bwd_noalloc (documented there).
  */
 #ifndef VITA_HIP_H
 #define VITA_HIP_H
@@ -112,6 +113,18 @@ int vita_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const flo
                        const float* dx_in, float* dx_out, int64_t lddx, void* dx_bf16,
                        int64_t ld_dxb, float* dgamma, float* dbeta, float* partial, int64_t rows,
                        int64_t d, void* stream);
+
+/* vita_layernorm_bwd for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results (bit-identical: the
+ * same kernels run) minus `partial`: the dgamma / dbeta partials live in a file-scope device array of the library,
+ * 12 MiB per GPU, held until the process ends.  Limit: d <= 2048 (VITA_ERR_UNSUPPORTED beyond, nothing launched).
+ * Calls no hipMalloc / hipFree or any allocating routine.  Every call on one GPU shares that GPU's array: calls that
+ * overlap on one GPU (two streams) race - serialise them. */
+int vita_layernorm_bwd_noalloc(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx,
+                               const float* gamma, const float* mean, const float* rstd,
+                               const float* dx_in, float* dx_out, int64_t lddx, void* dx_bf16,
+                               int64_t ld_dxb, float* dgamma, float* dbeta, int64_t rows, int64_t d,
+                               void* stream);
 
 /* ------------------------------------------------------------------ masking (integer-exact)
  * Masker.random_masking (utils/imaging_model_related.py:255-286) with the noise passed in:

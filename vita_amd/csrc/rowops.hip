@@ -252,10 +252,9 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __rest
   }
 }
 
-extern "C" int vita_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx,
-                                  const float* gamma, const float* mean, const float* rstd, const float* dx_in,
-                                  float* dx_out, int64_t lddx, void* dx_bf16, int64_t ld_dxb, float* dgamma,
-                                  float* dbeta, float* partial, int64_t rows, int64_t d, void* stream) {
+static int ln_bwd_impl(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* gamma,
+                       const float* mean, const float* rstd, const float* dx_in, float* dx_out, int64_t lddx, void* dx_bf16,
+                       int64_t ld_dxb, float* dgamma, float* dbeta, float* partial, int64_t rows, int64_t d, void* stream) {
   VITA_REQUIRE(dy && x && gamma && mean && rstd && dx_out && dgamma && dbeta && partial);
   VITA_REQUIRE(rows > 0 && d > 0 && d <= LN_MAXV * 256 && lddx <= LN_MAXV * 256);
   VITA_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && lddx >= d && ldx >= ((d + 3) / 4) * 4 && lddy >= ((d + 3) / 4) * 4);
@@ -276,6 +275,47 @@ extern "C" int vita_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype
                      nblk, (int)d, dgamma, dbeta);
   VITA_CHECK_LAUNCH("vita_layernorm_bwd_reduce");
   return VITA_OK;
+}
+extern "C" int vita_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx,
+                                  const float* gamma, const float* mean, const float* rstd, const float* dx_in,
+                                  float* dx_out, int64_t lddx, void* dx_bf16, int64_t ld_dxb, float* dgamma,
+                                  float* dbeta, float* partial, int64_t rows, int64_t d, void* stream) {
+  return ln_bwd_impl(dy, lddy, dy_dtype, x, ldx, gamma, mean, rstd, dx_in, dx_out, lddx, dx_bf16, ld_dxb, dgamma, dbeta, partial,
+                     rows, d, stream);
+}
+
+// The same backward for callers that cannot allocate: the dgamma / dbeta partials ([2][nblk][d] fp32, every element the
+// reduce kernel reads is written by the first kernel of the same call, so nothing needs clearing) live in a file-scope
+// device array instead of a caller-provided buffer.  Each GPU holds its own copy of the array (12 MiB, until the process
+// ends); its device address is looked up once per device, with that device current, and only that address - never the
+// array's name, which on the host is a stand-in and not a device address - is passed to the kernels.  Every call on
+// one GPU shares that GPU's array: calls that overlap on one GPU (two streams) race.
+#define LN_NOALLOC_MAX_D 2048
+#define LN_SCRATCH_FLOATS (2 * LN_BWD_MAXBLK * LN_NOALLOC_MAX_D)
+static __device__ __align__(256) float ln_bwd_scratch[LN_SCRATCH_FLOATS];
+static float* ln_scratch_ptr[VITA_MAX_DEVICES];
+static hipError_t ln_scratch_err[VITA_MAX_DEVICES];
+extern "C" int vita_layernorm_bwd_noalloc(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx,
+                                          const float* gamma, const float* mean, const float* rstd, const float* dx_in,
+                                          float* dx_out, int64_t lddx, void* dx_bf16, int64_t ld_dxb, float* dgamma,
+                                          float* dbeta, int64_t rows, int64_t d, void* stream) {
+  if (d > LN_NOALLOC_MAX_D || rows <= 0 || 2 * vita_layernorm_bwd_nblk(rows) * d > LN_SCRATCH_FLOATS) {
+    vita_set_error("vita_layernorm_bwd_noalloc: d exceeds the built-in scratch (d <= 2048); use vita_layernorm_bwd with a caller buffer",
+                   hipSuccess);
+    return VITA_ERR_UNSUPPORTED;
+  }
+  const int dev = vita_cur_device();
+  VITA_ONCE_PER_DEVICE({
+    void* p = nullptr;
+    ln_scratch_err[dev] = hipGetSymbolAddress(&p, HIP_SYMBOL(ln_bwd_scratch));
+    ln_scratch_ptr[dev] = ln_scratch_err[dev] == hipSuccess ? (float*)p : nullptr;
+  });
+  if (!ln_scratch_ptr[dev]) {
+    vita_set_error("vita_layernorm_bwd_noalloc: hipGetSymbolAddress", ln_scratch_err[dev]);
+    return VITA_ERR_LAUNCH;
+  }
+  return ln_bwd_impl(dy, lddy, dy_dtype, x, ldx, gamma, mean, rstd, dx_in, dx_out, lddx, dx_bf16, ld_dxb, dgamma, dbeta,
+                     ln_scratch_ptr[dev], rows, d, stream);
 }
 
 // ------------------------------------------------------------------------------------- argsort + mask
