@@ -395,6 +395,44 @@ def test_gemm256_epilogues(ops, variant):
     assert torch.equal(c5.cpu(), 2.0 * Bm)
 
 
+@pytest.mark.parametrize("variant", [108, 110, 112])
+@pytest.mark.parametrize("m,n,k", [(128, 192, 64), (700, 1088, 1120), (1000, 420, 200), (513, 3360, 1088), (2500, 1040, 4112),
+                                   (13826, 1088, 136)])
+def test_gemm128x_two_workgroups_per_cu(ops, variant, m, n, k):
+    """The 128-row variant of the LDS-DMA kernel (4 waves, 128 x (16 * (variant - 100)) x 64 tiles, stages small enough
+    for two workgroups per CU): k-contiguous operands with padded leading dimensions and ragged M / N / K, and every
+    epilogue (bias + GELU with the saved derivative, bias + residual fp32, GELU-backward factor, alpha)."""
+    torch.manual_seed(m + n + k + variant)
+    A = bf(torch.randn(m, k)); B = bf(torch.randn(n, k) * 0.1)
+    ref = A.float() @ B.float().t()
+    a, lda = _mk_operand(A, m, k, 0, ld_pad=8)
+    b, ldb = _mk_operand(B, n, k, 0, ld_pad=0)
+    ldc = n + 8
+    c = torch.full((m, ldc), float("nan"), device="cuda")
+    ops.gemm(dev(a), dev(b), c, m, n, k, lda, ldb, ldc, variant=variant)
+    out = c.cpu()
+    assert torch.isnan(out[:, n:]).all()               # nothing written past n
+    assert _rel(out[:, :n], ref) < 1e-5
+    if n % 8:
+        return
+    bias = torch.randn(n)
+    pre = ref + bias
+    cb = torch.empty(m, n, dtype=torch.bfloat16, device="cuda"); u = torch.empty_like(cb)
+    ops.gemm(dev(a), dev(b), cb, m, n, k, lda, ldb, n, bias=dev(bias), epilogue=ops.EPI_GELU, aux_out=u, variant=variant)
+    torch.testing.assert_close(u.cpu().float(), _gelu_grad(pre), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(cb.cpu().float(), torch.nn.functional.gelu(pre), rtol=2e-2, atol=2e-2)
+    res = torch.randn(m, n)
+    c2 = torch.empty(m, n, device="cuda")
+    ops.gemm(dev(a), dev(b), c2, m, n, k, lda, ldb, n, bias=dev(bias), epilogue=ops.EPI_RESIDUAL, aux_in=dev(res), ld_aux=n,
+             variant=variant)
+    torch.testing.assert_close(c2.cpu(), pre + res, rtol=1e-3, atol=5e-3)
+    uu = bf(_gelu_grad(torch.randn(m, n)))
+    c3 = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+    ops.gemm(dev(a), dev(b), c3, m, n, k, lda, ldb, n, epilogue=ops.EPI_GELU_BWD, aux_in=dev(uu), ld_aux=n, alpha=0.5,
+             variant=variant)
+    torch.testing.assert_close(c3.cpu().float(), 0.5 * ref * uu.float(), rtol=2e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize("variant", [8, 10, 12, 13, 14, 16])
 @pytest.mark.parametrize("split_k", [1, 3])
 def test_gemm256_wgrad_maps(ops, variant, split_k):

@@ -34,10 +34,15 @@ def run(name, m, n, k, la, lb, variants, out_f32=False, epi=0, split_k=1):
 if __name__ == "__main__":
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 13826
     V = [0, 8, 10, 12, 13, 14, 16]
-    run("qkv", M, 3360, 1088, 0, 0, V)
-    run("proj", M, 1088, 1120, 0, 0, V, out_f32=True, epi=ops.EPI_RESIDUAL)
-    run("fc1", M, 4160, 1088, 0, 0, V, epi=ops.EPI_GELU)
-    run("fc2", M, 1088, 4160, 0, 0, V, out_f32=True, epi=ops.EPI_RESIDUAL)
+    V0 = V + [108, 110, 112]
+    run("qkv", M, 3360, 1088, 0, 0, V0)
+    run("proj", M, 1088, 1120, 0, 0, V0, out_f32=True, epi=ops.EPI_RESIDUAL)
+    run("fc1", M, 4160, 1088, 0, 0, V0, epi=ops.EPI_GELU)
+    run("fc2", M, 1088, 4160, 0, 0, V0, out_f32=True, epi=ops.EPI_RESIDUAL)
+    run("du00", M, 4160, 1088, 0, 0, V0, epi=ops.EPI_GELU_BWD)
+    run("dln2_00", M, 1088, 4160, 0, 0, V0)
+    run("do00", M, 1120, 1088, 0, 0, V0)
+    run("dln1_00", M, 1088, 3360, 0, 0, V0)
     run("du", M, 4160, 1088, 0, 1, V, epi=ops.EPI_GELU_BWD)
     run("dln2", M, 1088, 4160, 0, 1, V)
     run("do", M, 1120, 1088, 0, 1, V)
@@ -46,5 +51,5 @@ if __name__ == "__main__":
     run("fc1w", 4160, 1088, M, 1, 1, V, split_k=3)
     run("projw", 1088, 1120, M, 1, 1, V, split_k=8)
     run("qkvw", 3360, 1088, M, 1, 1, V, split_k=3)
-    run("sq4k", 4096, 4096, 4096, 0, 0, V)
-    run("sq8k", 8192, 8192, 8192, 0, 0, V)
+    run("sq4k", 4096, 4096, 4096, 0, 0, V0)
+    run("sq8k", 8192, 8192, 8192, 0, 0, V0)

@@ -94,6 +94,13 @@ struct VitaPerDeviceOnce { std::once_flag f[VITA_MAX_DEVICES]; };
     std::call_once(once__.f[vita_cur_device()], [&]() { __VA_ARGS__; });     \
   } while (0)
 
+// hipFuncSetAttribute(fn, MaxDynamicSharedMemorySize, lds) once per device for the call site that owns `once`
+// (the kernel's address is taken by the caller, outside any lambda: hipcc's host pass otherwise drops the launch
+// stubs of all but the first instantiation referenced from one function)
+static inline void vita_set_max_lds_once(VitaPerDeviceOnce& once, const void* fn, int lds) {
+  std::call_once(once.f[vita_cur_device()], [=]() { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
+}
+
 void vita_set_error(const char* what, hipError_t e);
 #define VITA_CHECK_LAUNCH(name)                      \
   do {                                               \

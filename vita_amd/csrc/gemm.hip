@@ -287,7 +287,8 @@ extern "C" int vita_gemm_bf16_ex(const vita_gemm_desc* dp, int32_t variant, void
   if (variant != 1) {
     const bool ok = vita_gemm256_supported(d);
     if (variant > 1) {
-      VITA_REQUIRE(ok && (variant == 8 || variant == 10 || variant == 12 || variant == 13 || variant == 14 || variant == 16));
+      VITA_REQUIRE(ok && (variant == 8 || variant == 10 || variant == 12 || variant == 13 || variant == 14 || variant == 16 ||
+                          variant == 108 || variant == 110 || variant == 112));
       return vita_gemm256_launch(d, variant, (hipStream_t)stream);
     }
     // large un-batched problems: whichever kernel needs fewer (weighted) rounds of workgroups

@@ -42,10 +42,11 @@ __device__ __forceinline__ uint32_t g2_f(int r) { return (r & 3) | (((r >> 3) & 
 // K-tile; pieces past the image write zeros into the unused tail of the 32 KiB region.
 __device__ __forceinline__ uint32_t g2_sgpr(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
-template <int LAYOUT, int FREE>
+template <int LAYOUT, int FREE, int NWAVE = 8>
 struct G2Loader {
   static constexpr int NPIECE = LAYOUT == 0 ? FREE / 8 : 32;
-  static constexpr int PPW = 4;
+  static constexpr int PPW = (NPIECE + NWAVE - 1) / NWAVE;     // 4 with 8 waves; the region holds PPW * NWAVE KiB
+  static constexpr int BYTES = PPW * NWAVE * 1024;
   uint32_t voff[PPW];
   uint32_t base_lo, base_hi, bytes, kstep;   // wave-uniform (SGPRs)
   int kchunk;   // LAYOUT 0: k element offset of this lane's 16-B chunk inside a K-tile
@@ -64,7 +65,7 @@ struct G2Loader {
       kchunk = clog * 8;
 #pragma unroll
       for (int i = 0; i < PPW; ++i) {
-        const int p = wave + 8 * i;
+        const int p = wave + NWAVE * i;
         const int row = p * 8 + (lane >> 3);
         voff[i] = p < NPIECE ? (uint32_t)(row * ld * 2 + clog * 16) : G2_OOB;
       }
@@ -76,7 +77,7 @@ struct G2Loader {
       kchunk = 0;
 #pragma unroll
       for (int i = 0; i < PPW; ++i) {
-        const int p = wave + 8 * i;
+        const int p = wave + NWAVE * i;
         const int krow = 2 * p + (lane >> 5);
         const int pc = (lane & 31) >> 1, half = lane & 1;
         const int lc = pc ^ (int)g2_f(krow);
@@ -97,7 +98,7 @@ struct G2Loader {
   __device__ __forceinline__ bool keep(int kt) const { return LAYOUT != 0 || (kt * G2_BK + kchunk < K); }
   // piece i (0..3) of this wave; img = LDS address of this operand's 32 KiB region in the target stage
   __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, bool kp, int i, char* img, int wave) const {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(img + (wave + 8 * i) * 1024), 16, kp ? voff[i] : G2_OOB, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(img + (wave + NWAVE * i) * 1024), 16, kp ? voff[i] : G2_OOB, 0, 0, 0);
   }
 };
 
@@ -122,9 +123,10 @@ struct G2Frags {
       }
     }
   }
-  __device__ __forceinline__ void toggle() {
+  // delta = +stage bytes when moving from stage 0 to stage 1, -stage bytes back
+  __device__ __forceinline__ void toggle(int delta) {
 #pragma unroll
-    for (int j = 0; j < (LAYOUT == 0 ? 2 : NFR); ++j) b[j] ^= G2_STAGE;
+    for (int j = 0; j < (LAYOUT == 0 ? 2 : NFR); ++j) b[j] += delta;
   }
   // ASM: issue the LDS reads as inline asm.  hipcc puts s_waitcnt vmcnt(0) in front of every
   // ds_read_b64_tr_b16 builtin while an LDS-DMA is in flight (it cannot tell the DMA's LDS write from the
@@ -172,15 +174,20 @@ __device__ __forceinline__ void g2_sync_all() {
 // the rest (the two waves of a SIMD are w and w+4, so an odd NF still balances per SIMD).
 // ATOMIC: fp32 C accumulated with atomics through the segment maps (split-K weight gradients); the MFMA
 // is then issued un-swapped so that one accumulator register covers 4 rows x 64 contiguous bytes.
-template <int LA, int LB, int NF, bool ATOMIC>
+// NWM = waves along M: 4 -> 256-row tiles, 8 waves, two 64 KiB stages, one workgroup per CU; 2 -> 128-row tiles, 4 waves,
+// stages of 16 KiB (A) + NF * 2 KiB (B) (NF <= 12: 80 KiB), so that TWO workgroups share a CU and one's epilogue store
+// tail runs under the other's main loop (k-contiguous operands only).
+template <int LA, int LB, int NF, bool ATOMIC, int NWM>
 __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(const Gemm2Params P) {
   constexpr int NFW = (NF + 1) / 2;
   constexpr bool ASMR = LA == 1 || LB == 1;
+  constexpr int NWAVE = 2 * NWM, BM = 64 * NWM;
+  static_assert(NWM == 4 || (LA == 0 && LB == 0 && !ATOMIC), "the 128-row variant handles k-contiguous operands only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const vita_gemm_desc& d = P.d;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 3, wn = wave >> 2;
+  const int wm = wave % NWM, wn = wave / NWM;
   const int nfw = wn == 0 ? NFW : NF - NFW;
 
   // grouped, XCD-aware raster
@@ -195,20 +202,24 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(const Gemm2Param
     tn = in_g / gm;
   }
   const int split = blockIdx.y;
-  const int64_t m0 = (int64_t)tm * G2_BM, n0 = (int64_t)tn * (NF * 16);
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * (NF * 16);
   const int kt_total = (int)((d.k + G2_BK - 1) / G2_BK);
   const int kt_begin = split * P.k_tiles_per_split;
   int kt_end = kt_begin + P.k_tiles_per_split; if (kt_end > kt_total) kt_end = kt_total;
   const int nkt = kt_end - kt_begin;
 
-  G2Loader<LA, G2_BM> la;
-  G2Loader<LB, NF * 16> lb;
+  typedef G2Loader<LA, BM, NWAVE> LoaderA;
+  typedef G2Loader<LB, NF * 16, NWAVE> LoaderB;
+  constexpr int BOFF = LoaderA::BYTES, STAGE = BOFF + LoaderB::BYTES;   // 32 KiB + 32 KiB with 8 waves
+  constexpr int PA = LoaderA::PPW, PB = LoaderB::PPW, NDMA = PA + PB;
+  LoaderA la;
+  LoaderB lb;
   la.init((const uint16_t*)d.a, m0, d.m, d.k, d.lda, wave, lane);
   lb.init((const uint16_t*)d.b, n0, d.n, d.k, d.ldb, wave, lane);
   G2Frags<LA, 4> fa;
   G2Frags<LB, NFW> fb;
   fa.init(wm * 4, 0, lane);
-  fb.init(wn * NFW, G2_BOFF, lane);
+  fb.init(wn * NFW, BOFF, lane);
 
   f32x4 acc[4][NFW];
 #pragma unroll
@@ -244,7 +255,9 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(const Gemm2Param
       const __amdgpu_buffer_rsrc_t ra = la.rsrc(kt_begin), rb = lb.rsrc(kt_begin);
       const bool ka = la.keep(kt_begin), kb = lb.keep(kt_begin);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { la.issue(ra, ka, i, smem, wave); lb.issue(rb, kb, i, smem + G2_BOFF, wave); }
+      for (int i = 0; i < PA; ++i) la.issue(ra, ka, i, smem, wave);
+#pragma unroll
+      for (int i = 0; i < PB; ++i) lb.issue(rb, kb, i, smem + BOFF, wave);
     }
     g2_sync_all();
     {
@@ -252,7 +265,9 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(const Gemm2Param
       const __amdgpu_buffer_rsrc_t ra = la.rsrc(kt_begin + 1), rb = lb.rsrc(kt_begin + 1);
       const bool ka = la.keep(kt_begin + 1), kb = lb.keep(kt_begin + 1);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { la.issue(ra, ka, i, smem + G2_STAGE, wave); lb.issue(rb, kb, i, smem + G2_STAGE + G2_BOFF, wave); }
+      for (int i = 0; i < PA; ++i) la.issue(ra, ka, i, smem + STAGE, wave);
+#pragma unroll
+      for (int i = 0; i < PB; ++i) lb.issue(rb, kb, i, smem + STAGE + BOFF, wave);
     }
     G2_READ_A(0, a0); G2_READ_B(0, b0, 0, NFW);
     for (int t = 0; t + 1 < nkt; ++t) {
@@ -260,32 +275,32 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(const Gemm2Param
       // K-tile t+1 has landed (its DMA was issued one K-tile ago) - for every wave; every wave is also
       // done reading this stage, which K-tile t+2 may now overwrite
       g2_sync_all();
-      fa.toggle(); fb.toggle();
+      fa.toggle((t & 1) ? -STAGE : STAGE); fb.toggle((t & 1) ? -STAGE : STAGE);
       const int kt2 = kt_begin + t + 2;
       const __amdgpu_buffer_rsrc_t ra = la.rsrc(kt2), rb = lb.rsrc(kt2);
       const bool ka = la.keep(kt2), kb = lb.keep(kt2);
-      char* st = smem + (t & 1) * G2_STAGE;
+      char* st = smem + (t & 1) * STAGE;
       // ---- phase 2: MFMAs of k-step 1; DMA of K-tile t+2 and the reads of (t+1, k-step 0) spread between them
 #pragma unroll
       for (int j = 0; j < NFW; ++j) {
-        if constexpr (NFW >= 7) {
+        if constexpr (NFW >= 7 && NWM == 4) {
           if (j == 0) { la.issue(ra, ka, 0, st, wave); la.issue(ra, ka, 1, st, wave); }
           if (j == 1) la.issue(ra, ka, 2, st, wave);
           if (j == 2) la.issue(ra, ka, 3, st, wave);
-          if (j == 3) lb.issue(rb, kb, 0, st + G2_BOFF, wave);
-          if (j == 4) lb.issue(rb, kb, 1, st + G2_BOFF, wave);
-          if (j == 5) lb.issue(rb, kb, 2, st + G2_BOFF, wave);
-          if (j == 6) lb.issue(rb, kb, 3, st + G2_BOFF, wave);
+          if (j == 3) lb.issue(rb, kb, 0, st + BOFF, wave);
+          if (j == 4) lb.issue(rb, kb, 1, st + BOFF, wave);
+          if (j == 5) lb.issue(rb, kb, 2, st + BOFF, wave);
+          if (j == 6) lb.issue(rb, kb, 3, st + BOFF, wave);
           if (j == 2) { G2_READ_A(0, a0); }
           if (j == 3) { G2_READ_B(0, b0, 0, 3); }
           if (j == 4) { G2_READ_B(0, b0, 3, NFW); }
         } else {
-          // narrow tiles (NFW = 4..6 MFMA groups per k-step): DMA instruction i of the eight goes to group i*NFW/8, the
-          // fragment reads of the next K-tile's first k-step to the first three groups
+          // narrow tiles (NFW = 4..6 MFMA groups per k-step): DMA instruction i of the NDMA goes to group i*NFW/NDMA,
+          // the fragment reads of the next K-tile's first k-step to the first three groups
 #pragma unroll
-          for (int i = 0; i < 8; ++i)
-            if ((i * NFW) / 8 == j) {
-              if (i < 4) la.issue(ra, ka, i, st, wave); else lb.issue(rb, kb, i - 4, st + G2_BOFF, wave);
+          for (int i = 0; i < NDMA; ++i)
+            if ((i * NFW) / NDMA == j) {
+              if (i < PA) la.issue(ra, ka, i, st, wave); else lb.issue(rb, kb, i - PA, st + BOFF, wave);
             }
           if (j == 0) { G2_READ_A(0, a0); }
           if (j == 1) { G2_READ_B(0, b0, 0, 2); }
@@ -489,26 +504,33 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(const Gemm2Param
 }
 
 // ---- host -------------------------------------------------------------------------------------------
-template <int LA, int LB, int NF, bool ATOMIC>
+template <int LA, int LB, int NF, bool ATOMIC, int NWM = 4>
 static int g2_launch(const vita_gemm_desc& d, hipStream_t s) {
+  constexpr int BM = 64 * NWM, NWAVE = 2 * NWM;
   Gemm2Params P;
   P.d = d;
-  P.tiles_m = (int)((d.m + G2_BM - 1) / G2_BM);
+  P.tiles_m = (int)((d.m + BM - 1) / BM);
   P.tiles_n = (int)((d.n + NF * 16 - 1) / (NF * 16));
   const int kt_total = (int)((d.k + G2_BK - 1) / G2_BK);
   P.k_tiles_per_split = (kt_total + d.split_k - 1) / d.split_k;
   const int splits = (kt_total + P.k_tiles_per_split - 1) / P.k_tiles_per_split;
   dim3 grid((unsigned)(P.tiles_m * P.tiles_n), (unsigned)splits, 1);
-  constexpr size_t stage_bytes = 2 * G2_STAGE, epi_bytes = 8 * 32 * (((NF + 1) / 2) * 16 + 4) * 4;
+  // = 2 * (G2Loader<LA, BM, NWAVE>::BYTES + G2Loader<LB, NF * 16, NWAVE>::BYTES), spelled out: naming the device-side
+  // loader class here makes hipcc's host pass drop launch stubs
+  constexpr int npa = LA == 0 ? BM / 8 : 32, npb = LB == 0 ? NF * 2 : 32;
+  constexpr size_t stage_bytes = 2 * 1024 * (size_t)(((npa + NWAVE - 1) / NWAVE + (npb + NWAVE - 1) / NWAVE) * NWAVE);
+  constexpr size_t epi_bytes = NWAVE * 32 * (((NF + 1) / 2) * 16 + 4) * 4;
   const size_t lds = stage_bytes > epi_bytes ? stage_bytes : epi_bytes;
-  VITA_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)gemm256_kernel<LA, LB, NF, ATOMIC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL((gemm256_kernel<LA, LB, NF, ATOMIC>), grid, dim3(G2_THREADS), lds, s, P);
+  static VitaPerDeviceOnce once;
+  vita_set_max_lds_once(once, (const void*)gemm256_kernel<LA, LB, NF, ATOMIC, NWM>, (int)lds);
+  hipLaunchKernelGGL((gemm256_kernel<LA, LB, NF, ATOMIC, NWM>), grid, dim3(NWM * 128), lds, s, P);
   VITA_CHECK_LAUNCH("vita_gemm_bf16(256)");
   return VITA_OK;
 }
 
 // Cost model (arbitrary units, one unit ~ 16 output columns of a 256-row tile over the whole K):
 // rounds of 256 workgroups x (tile width + fixed per-tile overhead).  *nf_out = best tile width.
+bool vita_gemm128x_supported(const vita_gemm_desc& d);
 double vita_gemm256_cost(const vita_gemm_desc& d, int* nf_out) {
   const int64_t tm = (d.m + G2_BM - 1) / G2_BM;
   const int kt_total = (int)((d.k + G2_BK - 1) / G2_BK);
@@ -519,6 +541,7 @@ double vita_gemm256_cost(const vita_gemm_desc& d, int* nf_out) {
   // beside the weight-gradient GEMMs of the second stream, which already fill such a round: there the narrow tiles
   // measured +1.5 ms per step, so they are not candidates.
   static const bool wide_only = getenv("VITA_GEMM_WIDE_ONLY") && getenv("VITA_GEMM_WIDE_ONLY")[0] == '1';
+  static const bool no_128 = getenv("VITA_GEMM_NO128") && getenv("VITA_GEMM_NO128")[0] == '1';
   const int ncand = (wide_only || d.a_layout != 0 || d.b_layout != 0) ? 3 : 6;
   double best = 0; int best_nf = 0;
   for (int c = 0; c < ncand; ++c) {
@@ -526,6 +549,18 @@ double vita_gemm256_cost(const vita_gemm_desc& d, int* nf_out) {
     const int64_t rounds = (tm * tn * splits + 255) / 256;
     const double cost = (double)rounds * (cand[c] + (cand[c] < 13 ? G2_NARROW_OVERHEAD : 2.0)) / splits;
     if (best_nf == 0 || cost < best) { best = cost; best_nf = cand[c]; }
+  }
+  // 128-row tiles, two workgroups per CU (512 slots; a slot advances at half a CU's rate, a tile has half the rows: one
+  // round of 512 costs what a round of 256-row tiles of the same width costs, fixed part 2.5 units - fitted at
+  // M = 13826 / 46082, N = 1088..4160: qkv 116.7 -> 109.8 us, proj 65.7 -> 58.2, fc2 137.4 -> 118.9 at M = 13826)
+  if (!no_128 && !wide_only && vita_gemm128x_supported(d)) {
+    const int64_t tm1 = (d.m + 127) / 128;
+    for (int nf = 8; nf <= 12; nf += 2) {
+      const int64_t tn = (d.n + nf * 16 - 1) / (nf * 16);
+      const int64_t rounds = (tm1 * tn + 511) / 512;
+      const double cost = (double)rounds * (nf + 2.5);
+      if (cost < 0.97 * best) { best = cost; best_nf = 100 + nf; }
+    }
   }
   if (nf_out) *nf_out = best_nf;
   return best;
@@ -549,9 +584,24 @@ bool vita_gemm256_supported(const vita_gemm_desc& d) {
   return true;
 }
 
+// whether the 128-row, two-workgroups-per-CU variant (nf = 100 + tile width in fragments) can run this descriptor
+bool vita_gemm128x_supported(const vita_gemm_desc& d) {
+  const bool scalar_path = d.split_k > 1 || d.row_seg_phys || d.col_seg_phys || (d.n & 3);
+  return vita_gemm256_supported(d) && !scalar_path && d.a_layout == 0 && d.b_layout == 0;
+}
+
 int vita_gemm256_launch(const vita_gemm_desc& d, int nf, hipStream_t s) {
   const bool scalar_path = d.split_k > 1 || d.row_seg_phys || d.col_seg_phys || (d.n & 3);
   if (nf == 0) (void)vita_gemm256_cost(d, &nf);
+  if (nf > 100) {
+    if (!vita_gemm128x_supported(d)) {
+      vita_set_error("vita_gemm_bf16: the 128-row kernel needs k-contiguous operands and a plain epilogue path", hipSuccess);
+      return VITA_ERR_UNSUPPORTED;
+    }
+    if (nf == 108) return g2_launch<0, 0, 8, false, 2>(d, s);
+    if (nf == 110) return g2_launch<0, 0, 10, false, 2>(d, s);
+    if (nf == 112) return g2_launch<0, 0, 12, false, 2>(d, s);
+  }
 #define G2_CASE(LA, LB, AT)                                      \
   do {                                                           \
     if (nf == 8) return g2_launch<LA, LB, 8, AT>(d, s);          \
@@ -569,3 +619,21 @@ int vita_gemm256_launch(const vita_gemm_desc& d, int nf, hipStream_t s) {
   vita_set_error("vita_gemm_bf16: no large-tile kernel for this descriptor", hipSuccess);
   return VITA_ERR_UNSUPPORTED;
 }
+
+// Explicit instantiation of every kernel the launcher can pick: hipcc's host pass (ROCm 7.2) drops the launch stubs of
+// most implicit instantiations of this template (only the first one referenced from a function survived).
+#define G2_INST(LA, LB, AT, NWM)                                               \
+  template __global__ void gemm256_kernel<LA, LB, 8, AT, NWM>(const Gemm2Params);  \
+  template __global__ void gemm256_kernel<LA, LB, 10, AT, NWM>(const Gemm2Params); \
+  template __global__ void gemm256_kernel<LA, LB, 12, AT, NWM>(const Gemm2Params);
+#define G2_INST_WIDE(LA, LB, AT)                                               \
+  template __global__ void gemm256_kernel<LA, LB, 13, AT, 4>(const Gemm2Params);   \
+  template __global__ void gemm256_kernel<LA, LB, 14, AT, 4>(const Gemm2Params);   \
+  template __global__ void gemm256_kernel<LA, LB, 16, AT, 4>(const Gemm2Params);
+G2_INST(0, 0, false, 4) G2_INST_WIDE(0, 0, false)
+G2_INST(0, 1, false, 4) G2_INST_WIDE(0, 1, false)
+G2_INST(1, 1, false, 4) G2_INST_WIDE(1, 1, false)
+G2_INST(1, 1, true, 4) G2_INST_WIDE(1, 1, true)
+G2_INST(0, 0, false, 2)
+#undef G2_INST
+#undef G2_INST_WIDE
