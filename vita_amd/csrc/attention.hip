@@ -238,6 +238,11 @@ __device__ __forceinline__ int xcd_contiguous(int id, int n) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 #define ATT_NSLOT 3
+// Timing-only dissection builds of the dK/dV kernel (tools/attn_dissect.sh; results are INVALID when non-zero):
+// 1 = no dS stores, 2 = no in-loop LDS-DMA issue, 4 = no per-tile barrier, 8 = no exp, 16 = no P hand-off through LDS
+#ifndef ATT_DBG
+#define ATT_DBG 0
+#endif
 #define ATT_BWD_NSLOT 4   // the software-pipelined dK/dV kernel keeps tiles t .. t+3 in the ring
 #define ATT_DQDS_NSLOT 5  // ring depth of the streaming dQ kernel (K image + 8 dS tiles = 32 KiB per slot at hdp 224: all 160 KiB)
 
@@ -787,7 +792,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
       single_chain<HDP, NKS, 3>(sacc, smem, la, frag, [&](int s) {
         if (s == 0 || s == NKS - 1) pin_agpr(acc);
 #pragma unroll
-        for (int p = s; p <= 2 * NI; p += NKS) issue_piece(t + 2, pre, p);
+        for (int p = s; p <= 2 * NI; p += NKS) if (!(ATT_DBG & 2)) issue_piece(t + 2, pre, p);
       });
       const float* ls = reinterpret_cast<const float*>(smem + LC + slot * 256);
       uint32_t pw[8];
@@ -796,17 +801,19 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
         const f32x4 l4 = *reinterpret_cast<const f32x4*>(ls + 8 * rr + 4 * hh);
         float pe[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pe[k] = fast_exp2(__builtin_fmaf(sacc[4 * rr + k], c_exp2, l4[k]));
+        for (int k = 0; k < 4; ++k) pe[k] = (ATT_DBG & 8) ? __builtin_fmaf(sacc[4 * rr + k], c_exp2, l4[k]) : fast_exp2(__builtin_fmaf(sacc[4 * rr + k], c_exp2, l4[k]));
         pw[2 * rr] = cvt_pk(pe[0], pe[1]); pw[2 * rr + 1] = cvt_pk(pe[2], pe[3]);
       }
       char* xp = smem + xlane + (t & 1) * 2048;
-      *reinterpret_cast<u32x4*>(xp) = u32x4{pw[0], pw[1], pw[2], pw[3]};
-      *reinterpret_cast<u32x4*>(xp + 1024) = u32x4{pw[4], pw[5], pw[6], pw[7]};
+      if (!(ATT_DBG & 16)) {
+        *reinterpret_cast<u32x4*>(xp) = u32x4{pw[0], pw[1], pw[2], pw[3]};
+        *reinterpret_cast<u32x4*>(xp + 1024) = u32x4{pw[4], pw[5], pw[6], pw[7]};
+      }
       product(__builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]}), __builtin_bit_cast(bf16x8, u32x4{pw[4], pw[5], pw[6], pw[7]}));
       slot = slot + 1 == NSLOT ? 0 : slot + 1;
       la.advance(slot == 0 ? -(NSLOT - 1) * BUF : BUF);
       wait_one_tile_in_flight();    // tile t+1 has landed
-      ring_barrier();
+      if (!(ATT_DBG & 4)) ring_barrier();
     }
   } else {
     // step t: dS(t-1) from the partner's P(t-1), dK^T += Q^T(t-1) dS(t-1), dP chain of tile t (+ DMA of tile t+2)
@@ -828,7 +835,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
       const int prv = slot >= 1 ? slot - 1 : NSLOT - 1;              // slot of tile t-1
       const float* ds_ = reinterpret_cast<const float*>(smem + LC + prv * 256 + 128);
       const char* xp = smem + xlane + ((t + 1) & 1) * 2048;
-      const u32x4 pin0 = *reinterpret_cast<const u32x4*>(xp), pin1 = *reinterpret_cast<const u32x4*>(xp + 1024);
+      const u32x4 pin0 = (ATT_DBG & 16) ? u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u} : *reinterpret_cast<const u32x4*>(xp);
+      const u32x4 pin1 = (ATT_DBG & 16) ? pin0 : *reinterpret_cast<const u32x4*>(xp + 1024);
       uint32_t dw[8];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
@@ -839,7 +847,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
         dw[2 * rr] = cvt_pk(p0 * (dpacc[4 * rr] - d4[0]), p1 * (dpacc[4 * rr + 1] - d4[1]));
         dw[2 * rr + 1] = cvt_pk(p2 * (dpacc[4 * rr + 2] - d4[2]), p3 * (dpacc[4 * rr + 3] - d4[3]));
       }
-      if (ds_store && t >= 1) {       // dS^T of tile t-1, exactly the bf16 values the dK product consumes
+      if (ds_store && t >= 1 && !(ATT_DBG & 1)) {       // dS^T of tile t-1, exactly the bf16 values the dK product consumes
         const uint32_t toff = (uint32_t)(t0 + t - 1) * 2048u;      // wave-uniform
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{dw[0], dw[1], dw[2], dw[3]}, rsS, ds_lane, toff, 2);       // aux 2 = nt
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{dw[4], dw[5], dw[6], dw[7]}, rsS, ds_lane + 16, toff, 2);
@@ -850,13 +858,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
       single_chain<HDP, NKS, 3>(dpacc, smem, la, frag, [&](int s) {
         if (s == 0 || s == NKS - 1) pin_agpr(acc);
 #pragma unroll
-        for (int p = s; p <= 2 * NI; p += NKS) issue_piece(t + 2, pre, p);
+        for (int p = s; p <= 2 * NI; p += NKS) if (!(ATT_DBG & 2)) issue_piece(t + 2, pre, p);
       });
       slot = slot + 1 == NSLOT ? 0 : slot + 1;
       la.advance_rows(slot == 0 ? -(NSLOT - 1) * BUF : BUF);
       la.advance_tr(slot == 1 ? -(NSLOT - 1) * BUF : BUF);          // transposed reads address tile t's slot next step
       wait_one_tile_in_flight();
-      ring_barrier();
+      if (!(ATT_DBG & 4)) ring_barrier();
     }
   }
   dma_wait();      // the zero-filled prefetches past the last tile must land before the LDS is released
