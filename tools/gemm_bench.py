@@ -32,6 +32,11 @@ def run(name, m, n, k, la, lb, variants, out_f32=False, epi=0, split_k=1):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "sq":      # main-loop ceiling of each operand layout on large squares
+        for n in (4096, 8192):
+            for la, lb in ((0, 0), (0, 1), (1, 1)):
+                run(f"sq{n}", n, n, n, la, lb, [13, 14, 16])
+        sys.exit(0)
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 13826
     V = [0, 8, 10, 12, 13, 14, 16]
     V0 = V + [108, 110, 112]

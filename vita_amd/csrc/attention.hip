@@ -174,7 +174,7 @@ __device__ __forceinline__ void single_chain(f32x16& acc, const char* img, const
   for (int s = 0; s < NKS; ++s) {
     __builtin_amdgcn_sched_barrier(0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % DEPTH], b[s], acc, 0, 0, 0);
-    if (s + DEPTH < NKS) a[s % DEPTH] = la.row(img, s + DEPTH);
+    if (s + DEPTH < NKS && !(ATT_DBG & 64)) a[s % DEPTH] = la.row(img, s + DEPTH);
     between(s);
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -239,7 +239,8 @@ __device__ __forceinline__ int xcd_contiguous(int id, int n) {
 }
 #define ATT_NSLOT 3
 // Timing-only dissection builds of the dK/dV kernel (tools/attn_dissect.sh; results are INVALID when non-zero):
-// 1 = no dS stores, 2 = no in-loop LDS-DMA issue, 4 = no per-tile barrier, 8 = no exp, 16 = no P hand-off through LDS
+// 1 = no dS stores, 2 = no in-loop LDS-DMA issue, 4 = no per-tile barrier, 8 = no exp, 16 = no P hand-off through LDS,
+// 32 = no in-loop wait for tile arrival, 64 = LDS operand reads of the chains cut to the first 3 (rows) / 4 (transposed)
 #ifndef ATT_DBG
 #define ATT_DBG 0
 #endif
@@ -769,7 +770,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
     fr[0][0] = la.template tr_asm<0, 0, 0>(); fr[0][1] = la.template tr_asm<0, 1, 0>();
     static_for<NDT>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
-      if constexpr (i + 1 < NDT) {
+      if constexpr (ATT_DBG & 64) {
+        if constexpr (i == 0) { fr[1][0] = la.template tr_asm<1, 0, 0>(); fr[1][1] = la.template tr_asm<1, 1, 0>(); tr_wait<0>(); }
+      } else if constexpr (i + 1 < NDT) {
         fr[(i + 1) & 1][0] = la.template tr_asm<i + 1, 0, 0>(); fr[(i + 1) & 1][1] = la.template tr_asm<i + 1, 1, 0>();
         tr_wait<4>();
       } else {
@@ -812,7 +815,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
       product(__builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]}), __builtin_bit_cast(bf16x8, u32x4{pw[4], pw[5], pw[6], pw[7]}));
       slot = slot + 1 == NSLOT ? 0 : slot + 1;
       la.advance(slot == 0 ? -(NSLOT - 1) * BUF : BUF);
-      wait_one_tile_in_flight();    // tile t+1 has landed
+      if (!(ATT_DBG & 32)) wait_one_tile_in_flight();    // tile t+1 has landed
       if (!(ATT_DBG & 4)) ring_barrier();
     }
   } else {
@@ -863,7 +866,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
       slot = slot + 1 == NSLOT ? 0 : slot + 1;
       la.advance_rows(slot == 0 ? -(NSLOT - 1) * BUF : BUF);
       la.advance_tr(slot == 1 ? -(NSLOT - 1) * BUF : BUF);          // transposed reads address tile t's slot next step
-      wait_one_tile_in_flight();
+      if (!(ATT_DBG & 32)) wait_one_tile_in_flight();
       if (!(ATT_DBG & 4)) ring_barrier();
     }
   }
