@@ -26,6 +26,13 @@
 #include <type_traits>
 #include <utility>
 
+// Timing-only dissection builds of the dK/dV kernel (tools/attn_dissect.sh; results are INVALID when non-zero):
+// 1 = no dS stores, 2 = no in-loop LDS-DMA issue, 4 = no per-tile barrier, 8 = no exp, 16 = no P hand-off through LDS,
+// 32 = no in-loop wait for tile arrival, 64 = LDS operand reads of the chains cut to the first 3 (rows) / 4 (transposed)
+#ifndef ATT_DBG
+#define ATT_DBG 0
+#endif
+
 template <int HDP> struct AttCfg {
   static constexpr int RS = (HDP * 2 <= 256) ? 256 : 512;   // LDS row stride in bytes
   static constexpr int CPR = RS / 16;                        // 16-B chunks per LDS row (incl. pad)
@@ -238,12 +245,6 @@ __device__ __forceinline__ int xcd_contiguous(int id, int n) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 #define ATT_NSLOT 3
-// Timing-only dissection builds of the dK/dV kernel (tools/attn_dissect.sh; results are INVALID when non-zero):
-// 1 = no dS stores, 2 = no in-loop LDS-DMA issue, 4 = no per-tile barrier, 8 = no exp, 16 = no P hand-off through LDS,
-// 32 = no in-loop wait for tile arrival, 64 = LDS operand reads of the chains cut to the first 3 (rows) / 4 (transposed)
-#ifndef ATT_DBG
-#define ATT_DBG 0
-#endif
 #define ATT_BWD_NSLOT 4   // the software-pipelined dK/dV kernel keeps tiles t .. t+3 in the ring
 #define ATT_DQDS_NSLOT 5  // ring depth of the streaming dQ kernel (K image + 8 dS tiles = 32 KiB per slot at hdp 224: all 160 KiB)
 
