@@ -1,8 +1,11 @@
-"""Two ranks on two MI355X over RCCL (skipped on a box with fewer than two GPUs): the bucketed gradient all-reduce under
-the real autograd hooks + in-place kernel gradients, and the global-negative CLIP loss with its all-gather /
-reduce-scatter pair, against a serial single-process fake world computed on each rank's own GPU and against the
-reference's concatenated-batch fixture (g5 glob_*).  NOTE: the builder's box has one GPU, so this file has only ever
-been collected there, never executed; DESIGN.md section 6 says so."""
+"""Two ranks, real kernels: the bucketed gradient all-reduce under the real autograd hooks + in-place kernel gradients,
+and the global-negative CLIP loss with its all-gather / reduce-scatter pair, against a serial single-process fake world
+computed on each rank's own GPU and against the reference's concatenated-batch fixture (g5 glob_*).
+* two or more GPUs: one rank per GPU over RCCL (`test_two_ranks_over_rccl`).  NOTE: the builder's box has one GPU, so
+  that test has only ever been collected there, never executed; DESIGN.md section 6 says so.
+* one GPU: the same worker with both ranks sharing the GPU and gloo carrying the collectives
+  (`test_two_ranks_one_gpu_gloo`; RCCL refuses two ranks on one device).  Everything but the RCCL calls themselves is
+  the multi-rank product path: hooks, bucket launch guard, label offsets, cross terms, gradient scaling."""
 import os
 import socket
 
@@ -15,14 +18,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, backend):
     import sys
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(rank)
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
-                            device_id=torch.device("cuda", rank))
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", rank))
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
         import test_gpu_model as T
         from vita_amd import nn as vnn
@@ -73,13 +80,11 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_two_ranks_over_rccl(golden):
-    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
-        pytest.skip("needs two GPUs")
+def _run_two_ranks(golden, backend):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, ret, backend), nprocs=2, join=True)
     gl = float(golden("g5_clip.npz")["glob_loss"])
     for r in range(2):
         o = ret[r]
@@ -87,3 +92,15 @@ def test_two_ranks_over_rccl(golden):
         assert o["grad_err"] < 1e-3, o
         assert abs(o["clip_loss"] - gl) < 1e-4 * abs(gl) and o["clip_labels_ok"], o
         assert o["clip_logits_err"] < 1e-4 and o["clip_da_err"] < 1e-5 and o["clip_db_err"] < 1e-5, o
+
+
+def test_two_ranks_over_rccl(golden):
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _run_two_ranks(golden, "nccl")
+
+
+def test_two_ranks_one_gpu_gloo(golden):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    _run_two_ranks(golden, "gloo")
