@@ -191,6 +191,9 @@ def main():
     if os.environ.get("VITA_BENCH_DRYRUN") == "1":
         return dry_run(args)
 
+    if os.environ.get("VITA_BENCH_WATCHDOG"):               # seconds: dump every thread's stack and exit if still running
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["VITA_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
