@@ -8,6 +8,7 @@ computed on each rank's own GPU and against the reference's concatenated-batch f
   the multi-rank product path: hooks, bucket launch guard, label offsets, cross terms, gradient scaling."""
 import os
 import socket
+import time
 
 import numpy as np
 import pytest
@@ -23,6 +24,8 @@ def _worker(rank, world, port, ret, backend):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import faulthandler
+    faulthandler.dump_traceback_later(90, exit=True)
     if backend == "nccl":
         torch.cuda.set_device(rank)
         dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
@@ -84,7 +87,13 @@ def _run_two_ranks(golden, backend):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(2, port, ret, backend), nprocs=2, join=True)
+    ctx = mp.spawn(_worker, args=(2, port, ret, backend), nprocs=2, join=False)
+    deadline = time.time() + 100                    # a stuck rank must fail this test, not hang the session
+    while not ctx.join(timeout=5):
+        if time.time() > deadline:
+            for p in ctx.processes:
+                p.kill()
+            pytest.fail("two-rank worker still running after 100 s")
     gl = float(golden("g5_clip.npz")["glob_loss"])
     for r in range(2):
         o = ret[r]
