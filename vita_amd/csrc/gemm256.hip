@@ -17,6 +17,9 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef G2_DBG
+#define G2_DBG 0
+#endif
 #define G2_BM 256
 #define G2_BK 64
 #define G2_STAGE 65536
@@ -237,15 +240,18 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(const Gemm2Param
   // B fragments [lo, hi) of k-step KS into BF
 #define G2_READ_B(KS, BF, LO, HI) fb.template read_range<KS, ASMR, LO, HI, NFW>(smem, BF)
 #define G2_READ_A(KS, AF) fa.template read_range<KS, ASMR, 0, 4, 4>(smem, AF)
+  // in-loop reads; timing-only builds (G2_DBG, results INVALID) drop them: 1 = B fragments, 2 = A fragments
+#define G2_LREAD_B(KS, BF, LO, HI) do { if (!(G2_DBG & 1)) { G2_READ_B(KS, BF, LO, HI); } } while (0)
+#define G2_LREAD_A(KS, AF) do { if (!(G2_DBG & 2)) { G2_READ_A(KS, AF); } } while (0)
   // asm-read kernels: every fragment read issued so far has landed (the compiler cannot see those reads)
 #define G2_WAIT_FRAGS() do { if (ASMR) { __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); } } while (0)
   // phase 1: MFMAs of k-step 0 of the current K-tile; the fragments of its k-step 1 are read underneath
 #define G2_PHASE1()                                                  \
   G2_WAIT_FRAGS();                                                   \
   _Pragma("unroll") for (int j = 0; j < NFW; ++j) {                  \
-    if (j == 0) { G2_READ_A(1, a1); G2_READ_B(1, b1, 0, 1); }        \
-    if (j == 1) { G2_READ_B(1, b1, 1, 4); }                          \
-    if (j == 2) { G2_READ_B(1, b1, 4, NFW); }                        \
+    if (j == 0) { G2_LREAD_A(1, a1); G2_LREAD_B(1, b1, 0, 1); }      \
+    if (j == 1) { G2_LREAD_B(1, b1, 1, 4); }                         \
+    if (j == 2) { G2_LREAD_B(1, b1, 4, NFW); }                       \
     G2_MFMA_GROUP(j, a0, b0);                                        \
     __builtin_amdgcn_sched_barrier(0);                               \
   }
@@ -270,6 +276,13 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(const Gemm2Param
       for (int i = 0; i < PB; ++i) lb.issue(rb, kb, i, smem + STAGE + BOFF, wave);
     }
     G2_READ_A(0, a0); G2_READ_B(0, b0, 0, NFW);
+    if (G2_DBG) {
+      G2_WAIT_FRAGS();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a1[i] = a0[i];
+#pragma unroll
+      for (int j = 0; j < NFW; ++j) b1[j] = b0[j];
+    }
     for (int t = 0; t + 1 < nkt; ++t) {
       G2_PHASE1();
       // K-tile t+1 has landed (its DMA was issued one K-tile ago) - for every wave; every wave is also
@@ -291,9 +304,9 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(const Gemm2Param
           if (j == 4) lb.issue(rb, kb, 1, st + BOFF, wave);
           if (j == 5) lb.issue(rb, kb, 2, st + BOFF, wave);
           if (j == 6) lb.issue(rb, kb, 3, st + BOFF, wave);
-          if (j == 2) { G2_READ_A(0, a0); }
-          if (j == 3) { G2_READ_B(0, b0, 0, 3); }
-          if (j == 4) { G2_READ_B(0, b0, 3, NFW); }
+          if (j == 2) { G2_LREAD_A(0, a0); }
+          if (j == 3) { G2_LREAD_B(0, b0, 0, 3); }
+          if (j == 4) { G2_LREAD_B(0, b0, 3, NFW); }
         } else {
           // narrow tiles (NFW = 4..6 MFMA groups per k-step): DMA instruction i of the NDMA goes to group i*NFW/NDMA,
           // the fragment reads of the next K-tile's first k-step to the first three groups
@@ -302,9 +315,9 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(const Gemm2Param
             if ((i * NFW) / NDMA == j) {
               if (i < PA) la.issue(ra, ka, i, st, wave); else lb.issue(rb, kb, i - PA, st + BOFF, wave);
             }
-          if (j == 0) { G2_READ_A(0, a0); }
-          if (j == 1) { G2_READ_B(0, b0, 0, 2); }
-          if (j == 2) { G2_READ_B(0, b0, 2, NFW); }
+          if (j == 0) { G2_LREAD_A(0, a0); }
+          if (j == 1) { G2_LREAD_B(0, b0, 0, 2); }
+          if (j == 2) { G2_LREAD_B(0, b0, 2, NFW); }
         }
         G2_MFMA_GROUP(j, a1, b1);
         __builtin_amdgcn_sched_barrier(0);
@@ -321,6 +334,8 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(const Gemm2Param
 #undef G2_MFMA_GROUP
 #undef G2_READ_A
 #undef G2_READ_B
+#undef G2_LREAD_A
+#undef G2_LREAD_B
 
   // ---- epilogue: each wave stages its 64 x (nfw*16) fp32 block through a private 16 KiB LDS slice, 32
   // rows at a time, and writes whole rows (2 rows x up to 32 lanes x 16 B per wave-instruction)
