@@ -100,7 +100,8 @@ struct G2Loader {
   }
   __device__ __forceinline__ bool keep(int kt) const { return LAYOUT != 0 || (kt * G2_BK + kchunk < K); }
   // piece i (0..3) of this wave; img = LDS address of this operand's 32 KiB region in the target stage
-  __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, bool kp, int i, char* img, int wave) const {
+  __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, bool kp, int i, char* img, int wave, bool in_loop = false) const {
+    if ((G2_DBG & 8) && in_loop) return;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(img + (wave + NWAVE * i) * 1024), 16, kp ? voff[i] : G2_OOB, 0, 0, 0);
   }
 };
@@ -240,7 +241,8 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(const Gemm2Param
   // B fragments [lo, hi) of k-step KS into BF
 #define G2_READ_B(KS, BF, LO, HI) fb.template read_range<KS, ASMR, LO, HI, NFW>(smem, BF)
 #define G2_READ_A(KS, AF) fa.template read_range<KS, ASMR, 0, 4, 4>(smem, AF)
-  // in-loop reads; timing-only builds (G2_DBG, results INVALID) drop them: 1 = B fragments, 2 = A fragments
+  // in-loop reads; timing-only builds (G2_DBG, results INVALID) drop them: 1 = B fragments, 2 = A fragments;
+  // 4 = no per-K-tile barrier (wait kept), 16 = neither wait nor barrier, 8 = no in-loop LDS-DMA issue
 #define G2_LREAD_B(KS, BF, LO, HI) do { if (!(G2_DBG & 1)) { G2_READ_B(KS, BF, LO, HI); } } while (0)
 #define G2_LREAD_A(KS, AF) do { if (!(G2_DBG & 2)) { G2_READ_A(KS, AF); } } while (0)
   // asm-read kernels: every fragment read issued so far has landed (the compiler cannot see those reads)
@@ -287,7 +289,8 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(const Gemm2Param
       G2_PHASE1();
       // K-tile t+1 has landed (its DMA was issued one K-tile ago) - for every wave; every wave is also
       // done reading this stage, which K-tile t+2 may now overwrite
-      g2_sync_all();
+      if (G2_DBG & 4) { __builtin_amdgcn_s_waitcnt(0x0070); __builtin_amdgcn_sched_barrier(0); }     // wait, no barrier
+      else if (!(G2_DBG & 16)) g2_sync_all();                                                       // 16: neither
       fa.toggle((t & 1) ? -STAGE : STAGE); fb.toggle((t & 1) ? -STAGE : STAGE);
       const int kt2 = kt_begin + t + 2;
       const __amdgpu_buffer_rsrc_t ra = la.rsrc(kt2), rb = lb.rsrc(kt2);
@@ -297,13 +300,13 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(const Gemm2Param
 #pragma unroll
       for (int j = 0; j < NFW; ++j) {
         if constexpr (NFW >= 7 && NWM == 4) {
-          if (j == 0) { la.issue(ra, ka, 0, st, wave); la.issue(ra, ka, 1, st, wave); }
-          if (j == 1) la.issue(ra, ka, 2, st, wave);
-          if (j == 2) la.issue(ra, ka, 3, st, wave);
-          if (j == 3) lb.issue(rb, kb, 0, st + BOFF, wave);
-          if (j == 4) lb.issue(rb, kb, 1, st + BOFF, wave);
-          if (j == 5) lb.issue(rb, kb, 2, st + BOFF, wave);
-          if (j == 6) lb.issue(rb, kb, 3, st + BOFF, wave);
+          if (j == 0) { la.issue(ra, ka, 0, st, wave, true); la.issue(ra, ka, 1, st, wave, true); }
+          if (j == 1) la.issue(ra, ka, 2, st, wave, true);
+          if (j == 2) la.issue(ra, ka, 3, st, wave, true);
+          if (j == 3) lb.issue(rb, kb, 0, st + BOFF, wave, true);
+          if (j == 4) lb.issue(rb, kb, 1, st + BOFF, wave, true);
+          if (j == 5) lb.issue(rb, kb, 2, st + BOFF, wave, true);
+          if (j == 6) lb.issue(rb, kb, 3, st + BOFF, wave, true);
           if (j == 2) { G2_LREAD_A(0, a0); }
           if (j == 3) { G2_LREAD_B(0, b0, 0, 3); }
           if (j == 4) { G2_LREAD_B(0, b0, 3, NFW); }
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(G2_THREADS, 2) void gemm256_kernel(const Gemm2Param
 #pragma unroll
           for (int i = 0; i < NDMA; ++i)
             if ((i * NFW) / NDMA == j) {
-              if (i < PA) la.issue(ra, ka, i, st, wave); else lb.issue(rb, kb, i - PA, st + BOFF, wave);
+              if (i < PA) la.issue(ra, ka, i, st, wave, true); else lb.issue(rb, kb, i - PA, st + BOFF, wave, true);
             }
           if (j == 0) { G2_LREAD_A(0, a0); }
           if (j == 1) { G2_LREAD_B(0, b0, 0, 2); }
