@@ -40,6 +40,8 @@ if __name__ == "__main__":
     M = int(sys.argv[1]) if len(sys.argv) > 1 else 13826
     V = [0, 8, 10, 12, 13, 14, 16]
     V0 = V + [108, 110, 112]
+    if os.environ.get("GEMM_BENCH_V"):                   # e.g. GEMM_BENCH_V=0: the dispatcher's own choice only
+        V = V0 = [int(v) for v in os.environ["GEMM_BENCH_V"].split(",")]
     run("qkv", M, 3360, 1088, 0, 0, V0)
     run("proj", M, 1088, 1120, 0, 0, V0, out_f32=True, epi=ops.EPI_RESIDUAL)
     run("fc1", M, 4160, 1088, 0, 0, V0, epi=ops.EPI_GELU)
