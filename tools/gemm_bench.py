@@ -24,6 +24,10 @@ def run(name, m, n, k, la, lb, variants, out_f32=False, epi=0, split_k=1):
     if epi == ops.EPI_RESIDUAL: kw = dict(epilogue=epi, aux_in=torch.randn(m, n, device="cuda"), ld_aux=n, bias=torch.zeros(n, device="cuda"))
     if epi == ops.EPI_GELU_BWD: kw = dict(epilogue=epi, aux_in=torch.randn(m, n, device="cuda").to(torch.bfloat16), ld_aux=n)
     res = []
+    # the first measurements on freshly allocated operands read 5-20 % slow (page tables / clocks still warming up), which
+    # used to bias the first column (v0): run the first variant untimed until that has passed
+    for _ in range(30):
+        ops.gemm(a, b, c, m, n, k, a.shape[1], b.shape[1], n, a_layout=la, b_layout=lb, variant=variants[0], split_k=split_k, **kw)
     for v in variants:
         t = timeit(lambda: ops.gemm(a, b, c, m, n, k, a.shape[1], b.shape[1], n, a_layout=la, b_layout=lb, variant=v,
                                     split_k=split_k, **kw))
