@@ -568,7 +568,12 @@ double vita_gemm256_cost(const vita_gemm_desc& d, int* nf_out) {
   for (int c = 0; c < ncand; ++c) {
     const int64_t tn = (d.n + cand[c] * 16 - 1) / (cand[c] * 16);
     const int64_t rounds = (tm * tn * splits + 255) / 256;
-    const double cost = (double)rounds * (cand[c] + (cand[c] < 13 ? G2_NARROW_OVERHEAD : 2.0)) / splits;
+    // fixed part per tile.  The 208 / 224-column tiles also carry their lower main-loop efficiency (8192^3: 1201 / 1217
+    // against 1403 TFLOP/s at 256 columns, i.e. 13 -> 15.2 and 14 -> 16.1 units of work): without it the model preferred
+    // 224 columns wherever they saved a round (fc1 at M = 46082: 576 us against 518 us with 256); step -0.5 % at T = 50,
+    // -2.5 % in Stage II.  (Narrow tiles for the dgrad GEMMs re-measured in round 2: still +2.5 % on the step.)
+    const double fixed = cand[c] < 13 ? G2_NARROW_OVERHEAD : cand[c] == 13 ? 4.2 : cand[c] == 14 ? 4.1 : 2.0;
+    const double cost = (double)rounds * (cand[c] + fixed) / splits;
     if (best_nf == 0 || cost < best) { best = cost; best_nf = cand[c]; }
   }
   // 128-row tiles, two workgroups per CU (512 slots; a slot advances at half a CU's rate, a tile has half the rows: one
