@@ -43,22 +43,26 @@ extern "C" int vita_l2_normalize_bwd(const float* dy, const float* y, const floa
 }
 
 // ------------------------------------------------------------------------------------- small fp32 GEMM
-// C[m][n] = alpha * sum_k A(m,k) B(k,n) + beta * C ; layouts as vita_gemm_bf16.  64x64x16 tile, 4x4 per thread.
+// C[m][n] = alpha * sum_k A(m,k) B(k,n) + beta * C ; layouts as vita_gemm_bf16.  (16R)x(16R)x16 tile, RxR per thread:
+// R = 4 for large outputs; R = 2 / 1 when the output is small and the reduction long (projection heads: 32 x 1025 x 1025
+// is 17 workgroups of 65 serial K-steps with R = 4, 79 us; 130 workgroups with R = 1), so that the grid covers the chip.
+template <int R>
 __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                                     int m, int n, int k, int64_t lda, int64_t ldb, int64_t ldc, int la, int lb,
                                                     float alpha, float beta) {
-  __shared__ float As[16][64 + 1], Bs[16][64 + 1];
+  constexpr int T = 16 * R;
+  __shared__ float As[16][T + 1], Bs[16][T + 1];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  float acc[4][4] = {};
+  const int m0 = blockIdx.y * T, n0 = blockIdx.x * T;
+  float acc[R][R] = {};
   for (int k0 = 0; k0 < k; k0 += 16) {
-    for (int e = threadIdx.x; e < 1024; e += 256) {
+    for (int e = threadIdx.x; e < 16 * T; e += 256) {
       int kk, f;
-      if (la == 0) { kk = e & 15; f = e >> 4; } else { f = e & 63; kk = e >> 6; }
+      if (la == 0) { kk = e & 15; f = e >> 4; } else { f = e % T; kk = e / T; }
       float v = 0.f;
       if (m0 + f < m && k0 + kk < k) v = la == 0 ? A[(int64_t)(m0 + f) * lda + k0 + kk] : A[(int64_t)(k0 + kk) * lda + m0 + f];
       As[kk][f] = v;
-      if (lb == 0) { kk = e & 15; f = e >> 4; } else { f = e & 63; kk = e >> 6; }
+      if (lb == 0) { kk = e & 15; f = e >> 4; } else { f = e % T; kk = e / T; }
       v = 0.f;
       if (n0 + f < n && k0 + kk < k) v = lb == 0 ? B[(int64_t)(n0 + f) * ldb + k0 + kk] : B[(int64_t)(k0 + kk) * ldb + n0 + f];
       Bs[kk][f] = v;
@@ -66,21 +70,21 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const float* __restrict__ A,
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) {
-      float a[4], b[4];
+      float a[R], b[R];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
+      for (int i = 0; i < R; ++i) { a[i] = As[kk][ty * R + i]; b[i] = Bs[kk][tx * R + i]; }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < R; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        for (int j = 0; j < R; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < R; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = m0 + ty * 4 + i, c = n0 + tx * 4 + j;
+    for (int j = 0; j < R; ++j) {
+      const int r = m0 + ty * R + i, c = n0 + tx * R + j;
       if (r < m && c < n) {
         float* p = C + (int64_t)r * ldc + c;
         *p = alpha * acc[i][j] + (beta != 0.f ? beta * *p : 0.f);
@@ -91,8 +95,17 @@ extern "C" int vita_sgemm_f32(const float* a, const float* b, float* c, int64_t 
                               int64_t ldb, int64_t ldc, int32_t a_layout, int32_t b_layout, float alpha, float beta,
                               void* stream) {
   VITA_REQUIRE(a && b && c && m > 0 && n > 0 && k > 0 && m < (1 << 22) && n < (1 << 22));
-  hipLaunchKernelGGL(sgemm_kernel, dim3((unsigned)((n + 63) / 64), (unsigned)((m + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
-                     a, b, c, (int)m, (int)n, (int)k, lda, ldb, ldc, a_layout, b_layout, alpha, beta);
+  // the largest tile whose grid still has one workgroup per CU; the accumulation order over k is the same for every R
+  // (one thread owns an output element and walks k in order), so the result does not depend on the choice
+  const int64_t wg4 = ((n + 63) / 64) * ((m + 63) / 64), wg2 = ((n + 31) / 32) * ((m + 31) / 32);
+#define SGEMM_LAUNCH(R)                                                                                                        \
+  hipLaunchKernelGGL(sgemm_kernel<R>, dim3((unsigned)((n + 16 * R - 1) / (16 * R)), (unsigned)((m + 16 * R - 1) / (16 * R))),   \
+                     dim3(256), 0, (hipStream_t)stream, a, b, c, (int)m, (int)n, (int)k, lda, ldb, ldc, a_layout, b_layout,    \
+                     alpha, beta)
+  if (wg4 >= 256) SGEMM_LAUNCH(4);
+  else if (wg2 >= 256) SGEMM_LAUNCH(2);
+  else SGEMM_LAUNCH(1);
+#undef SGEMM_LAUNCH
   VITA_CHECK_LAUNCH("vita_sgemm_f32");
   return VITA_OK;
 }
