@@ -95,6 +95,7 @@ def _run_two_ranks(golden, backend):
                 p.kill()
             pytest.fail("two-rank worker still running after 100 s")
     gl = float(golden("g5_clip.npz")["glob_loss"])
+    assert ret[0]["launch_order"] == ret[1]["launch_order"], (ret[0]["launch_order"], ret[1]["launch_order"])   # RCCL needs one order
     for r in range(2):
         o = ret[r]
         assert o["buckets"] >= 2 and sorted(o["launch_order"]) == list(range(o["buckets"])), o     # each bucket exactly once
