@@ -113,12 +113,33 @@ def cpu_baseline(steps=3):
     return out, n_all
 
 
+def profiler_preloaded():
+    """Non-empty (the evidence) when this process runs under a GPU profiler's preload (rocprofv3 / rocprof)."""
+    pre = os.environ.get("LD_PRELOAD", "")
+    if any(t in pre.lower() for t in ("rocprof", "roctracer", "rocprofiler")):
+        return "LD_PRELOAD=" + pre
+    for k in os.environ:
+        if k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_")):
+            return k + " is set"
+    return ""
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` without an external launcher: this parent - which never touches the GPU - starts one
     rank per GPU through torch.distributed.run on 127.0.0.1 (the reference spawns its own ranks too: Lightning DDP,
     main.py:61), relays their output (rank 0 prints the JSON line) and exits with their status."""
     import socket
     import subprocess
+    why = profiler_preloaded()
+    if why:
+        # A profiler's preloaded library initialises the GPU before main() runs (rocprofv3 --pmc does), and starting
+        # the launcher from a GPU-initialised process is the exec hop this pool forbids.  Multi-rank profiling is the
+        # other way round: the launcher outside, the profiler per rank -
+        #   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --no-python \
+        #       rocprofv3 --kernel-trace --stats -d out -- python3 bench.py --gpus N ...
+        print(f"bench.py --gpus {n}: refusing to launch ranks from a profiled process ({why}); run the launcher outside "
+              "and the profiler per rank (see bench.py launch_ranks)", file=sys.stderr, flush=True)
+        return 3
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
@@ -236,6 +257,8 @@ def main():
                  "multi_categorical": {f"m{i}": [n] for i, n in enumerate(TAB_MULTI)}}
         model = MultimodalSimCLR(img_shape, imaging, tab, feats, temperature=0.1, lambda_0=0.5,
                                  gather_distributed=use_dist).cuda()
+        # a forced one-rank distributed run exercises the all-gather / reduce-scatter / loss all-reduce too
+        model.criterion.collectives_at_world1 = use_dist and world == 1
         opt = FlatAdam(model.parameters(), lr=3e-3, weight_decay=1e-4)
         reducer = BucketedAllReduce(opt) if use_dist else None
         tabs = torch.cat([torch.randn(B, TAB_NUM, device="cuda", generator=gen),

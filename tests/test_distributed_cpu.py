@@ -165,3 +165,29 @@ def test_bench_launches_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, VITA_BENCH_DRYRUN_FAIL_RANK="1"),
                        capture_output=True, text=True, timeout=240)
     assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_refuses_to_launch_ranks_under_a_profiler():
+    """Under rocprofv3 the preloaded tool library has initialised the GPU before main() runs; starting the rank launcher
+    from such a process is the exec hop the GPU pool forbids.  bench.py must refuse (exit 3, no child, no JSON line)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(VITA_BENCH_DRYRUN="1", ROCPROF_OUTPUT_PATH="/tmp/x")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=240)
+    assert r.returncode == 3 and "refusing to launch ranks" in r.stderr and not r.stdout.strip(), (r.returncode, r.stderr[-500:])
+
+
+def _host_staged(rank, world):
+    """all_reduce_any / BucketedAllReduce on host tensors under gloo: what the shared-GPU two-rank test relies on."""
+    from vita_amd.losses import all_reduce_any, device_collectives
+    assert not device_collectives(dist.group.WORLD)
+    t = torch.full((5,), float(rank + 1))
+    all_reduce_any(t, dist.group.WORLD)
+    return t.tolist()
+
+
+def test_all_reduce_any_host_path():
+    assert _run(_host_staged) == [[3.0] * 5, [3.0] * 5]

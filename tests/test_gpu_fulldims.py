@@ -50,6 +50,20 @@ def test_stage1_step_full_dims_vs_oracle():
     for k, g in grads.items():
         e = rel(named[k].grad, g)
         assert e < 2e-2, (k, e)
+    # The same step against the oracle with its bf16 rounding points on (O.ROUND_BF16: operands of every GEMM / attention
+    # product rounded where the kernels store bf16).  What is left is accumulation order and the few places the kernels
+    # keep more precision, so every gradient tensor must now agree to 5e-3 (measured: 0.7-0.8e-3, cls_token 2.4e-3) -
+    # an indexing / masking / padding bug that hides inside 2e-2 of fp32-vs-bf16 rounding cannot hide here.
+    grads_fp32 = {k: named[k].grad.detach().clone() for k in grads}
+    O.ROUND_BF16 = True
+    try:
+        ref_r, grads_r = O.stage1_train_step(imgs, {k: v.clone() for k, v in p.items()}, noise, {}, lr=1e-4, patch_size=(5, 8, 8),
+                                             enc_depth=6, enc_heads=5, dec_depth=2, dec_heads=5, mask_ratio=0.7)
+    finally:
+        O.ROUND_BF16 = False
+    assert abs(loss.item() - ref_r.item()) < 1e-3 * abs(ref_r.item()), (loss.item(), ref_r.item())
+    worst = max((rel(grads_fp32[k], g), k) for k, g in grads_r.items())
+    assert worst[0] < 5e-3, worst
     # Adam moved every weight by at most lr, in the oracle's direction
     for k in ("encoder_imaging.encoder.0.attn.qkv.weight", "decoder_imaging.decoder.network.1.mlp.fc2.weight",
               "encoder_imaging.patch_embed.proj.weight", "decoder_imaging.mask_token"):

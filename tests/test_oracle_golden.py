@@ -167,6 +167,65 @@ def test_block_restatement_vs_independent_formulations():
     torch.testing.assert_close(out, x1 + torch.nn.functional.linear(h, p["mlp.fc2.weight"], p["mlp.fc2.bias"]), rtol=1e-4, atol=1e-5)
 
 
+def test_block_restatement_vs_transformers_vit_layer():
+    """Third independent formulation of the (unpinned) timm Block: Hugging Face `ViTLayer` built from a LOCAL ViTConfig
+    (no from_pretrained, nothing fetched) with the oracle's weights copied in - q / k / v are the three row blocks
+    [q | k | v] of the fused qkv.weight.  Same pre-LN residual structure, exact-erf GELU, LayerNorm
+    eps 1e-5, softmax((q k^T) hd^-1/2) v.  Forward and every parameter gradient at 1e-5."""
+    transformers = pytest.importorskip("transformers")
+    from transformers import ViTConfig
+    from transformers.models.vit.modeling_vit import ViTLayer
+    D, H, N, B = 129, 3, 41, 2
+    cfg = ViTConfig(hidden_size=D, num_attention_heads=H, intermediate_size=4 * D, hidden_act="gelu", layer_norm_eps=1e-5,
+                    qkv_bias=True, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    cfg._attn_implementation = "eager"
+    layer = ViTLayer(cfg).eval()
+    p = {}
+    O.init_block(p, "", D, 4 * D, torch.Generator().manual_seed(5))
+    g = torch.Generator().manual_seed(6)
+    for k in list(p):
+        if k.endswith("bias"):
+            p[k] = torch.randn(p[k].shape, generator=g) * 0.1
+        if k.startswith("norm") and k.endswith("weight"):
+            p[k] = 1 + torch.randn(p[k].shape, generator=g) * 0.1
+    names = {n for n, _ in layer.named_parameters()}
+    qw, kw, vw = p["attn.qkv.weight"].split(D, dim=0)
+    qb, kb, vb = p["attn.qkv.bias"].split(D, dim=0)
+    if "attention.q_proj.weight" in names:           # transformers 5.x layout
+        m = {"attention.q_proj": (qw, qb), "attention.k_proj": (kw, kb), "attention.v_proj": (vw, vb),
+             "attention.o_proj": (p["attn.proj.weight"], p["attn.proj.bias"]),
+             "mlp.fc1": (p["mlp.fc1.weight"], p["mlp.fc1.bias"]), "mlp.fc2": (p["mlp.fc2.weight"], p["mlp.fc2.bias"])}
+    else:                                            # transformers 4.x layout
+        m = {"attention.attention.query": (qw, qb), "attention.attention.key": (kw, kb), "attention.attention.value": (vw, vb),
+             "attention.output.dense": (p["attn.proj.weight"], p["attn.proj.bias"]),
+             "intermediate.dense": (p["mlp.fc1.weight"], p["mlp.fc1.bias"]), "output.dense": (p["mlp.fc2.weight"], p["mlp.fc2.bias"])}
+    m["layernorm_before"] = (p["norm1.weight"], p["norm1.bias"])
+    m["layernorm_after"] = (p["norm2.weight"], p["norm2.bias"])
+    sd = {}
+    for k, (w, b) in m.items():
+        sd[k + ".weight"], sd[k + ".bias"] = w.clone(), b.clone()
+    assert set(sd) == names, sorted(names ^ set(sd))
+    layer.load_state_dict(sd, strict=True)
+    x = torch.randn(B, N, D, generator=g)
+    cot = torch.randn(B, N, D, generator=g)
+    ref = layer(x)
+    ref = ref[0] if isinstance(ref, (tuple, list)) else ref
+    (ref * cot).sum().backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    mine = O.block_forward(x, leaves, "", H)
+    (mine * cot).sum().backward()
+    torch.testing.assert_close(mine, ref, rtol=1e-5, atol=1e-5)
+    got = dict(layer.named_parameters())
+    qkv_ref_w = torch.cat([got[k + ".weight"].grad for k in list(m)[:3]], 0)
+    qkv_ref_b = torch.cat([got[k + ".bias"].grad for k in list(m)[:3]], 0)
+    torch.testing.assert_close(leaves["attn.qkv.weight"].grad, qkv_ref_w, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(leaves["attn.qkv.bias"].grad, qkv_ref_b, rtol=1e-4, atol=1e-5)
+    for mine_k, ref_k in (("attn.proj", list(m)[3]), ("mlp.fc1", list(m)[4]), ("mlp.fc2", list(m)[5]), ("norm1", "layernorm_before"),
+                          ("norm2", "layernorm_after")):
+        for t in ("weight", "bias"):
+            torch.testing.assert_close(leaves[f"{mine_k}.{t}"].grad, got[f"{ref_k}.{t}"].grad, rtol=1e-4, atol=1e-5)
+
+
 def test_g7_cine_normalization(golden):
     """image_normalization (reference function, utils/general.py:139-147) on the assembled (S,T,H,W) volume."""
     g = golden("g7_cine.npz")

@@ -294,28 +294,39 @@ extern "C" int vita_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype
 #define LN_SCRATCH_FLOATS (2 * LN_BWD_MAXBLK * LN_NOALLOC_MAX_D)
 static __device__ __align__(256) float ln_bwd_scratch[LN_SCRATCH_FLOATS];
 static float* ln_scratch_ptr[VITA_MAX_DEVICES];
-static hipError_t ln_scratch_err[VITA_MAX_DEVICES];
 extern "C" int vita_layernorm_bwd_noalloc(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx,
                                           const float* gamma, const float* mean, const float* rstd, const float* dx_in,
                                           float* dx_out, int64_t lddx, void* dx_bf16, int64_t ld_dxb, float* dgamma,
                                           float* dbeta, int64_t rows, int64_t d, void* stream) {
-  if (d > LN_NOALLOC_MAX_D || rows <= 0 || 2 * vita_layernorm_bwd_nblk(rows) * d > LN_SCRATCH_FLOATS) {
+  if (rows <= 0 || d <= 0) {
+    vita_set_error("vita_layernorm_bwd_noalloc: rows and d must be positive", hipSuccess);
+    return VITA_ERR_INVALID_ARG;
+  }
+  if (d > LN_NOALLOC_MAX_D || 2 * vita_layernorm_bwd_nblk(rows) * d > LN_SCRATCH_FLOATS) {
     vita_set_error("vita_layernorm_bwd_noalloc: d exceeds the built-in scratch (d <= 2048); use vita_layernorm_bwd with a caller buffer",
                    hipSuccess);
     return VITA_ERR_UNSUPPORTED;
   }
+  // The symbol's address is resolved on the FIRST call on a device (that call may also make the runtime load the code
+  // object: make it once outside graph capture); a failed lookup is not latched, the next call tries again.
   const int dev = vita_cur_device();
-  VITA_ONCE_PER_DEVICE({
+  if (dev < 0 || dev >= VITA_MAX_DEVICES) {
+    vita_set_error("vita_layernorm_bwd_noalloc: device index out of range", hipSuccess);
+    return VITA_ERR_INVALID_ARG;
+  }
+  float* scratch_ptr = __atomic_load_n(&ln_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+  if (!scratch_ptr) {
     void* p = nullptr;
-    ln_scratch_err[dev] = hipGetSymbolAddress(&p, HIP_SYMBOL(ln_bwd_scratch));
-    ln_scratch_ptr[dev] = ln_scratch_err[dev] == hipSuccess ? (float*)p : nullptr;
-  });
-  if (!ln_scratch_ptr[dev]) {
-    vita_set_error("vita_layernorm_bwd_noalloc: hipGetSymbolAddress", ln_scratch_err[dev]);
-    return VITA_ERR_LAUNCH;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(ln_bwd_scratch));
+    if (e != hipSuccess || !p) {
+      vita_set_error("vita_layernorm_bwd_noalloc: hipGetSymbolAddress", e);
+      return VITA_ERR_LAUNCH;
+    }
+    scratch_ptr = (float*)p;          // every thread that races here resolves the same per-device address
+    __atomic_store_n(&ln_scratch_ptr[dev], scratch_ptr, __ATOMIC_RELEASE);
   }
   return ln_bwd_impl(dy, lddy, dy_dtype, x, ldx, gamma, mean, rstd, dx_in, dx_out, lddx, dx_bf16, ld_dxb, dgamma, dbeta,
-                     ln_scratch_ptr[dev], rows, d, stream);
+                     scratch_ptr, rows, d, stream);
 }
 
 // ------------------------------------------------------------------------------------- argsort + mask

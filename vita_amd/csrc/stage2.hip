@@ -111,23 +111,28 @@ extern "C" int vita_tabular_embed_bwd(const float* dout, int64_t ldo, const floa
 
 // ------------------------------------------------------------------------------------- mean over tokens
 // out[b][c] = (1/N) sum_n x[b][n][c]   (y.mean(dim=1), models/MultimodalSimCLR.py:121,133).  A block = 16 column lanes
-// (one 16-B unit each) x 16 row lanes over a chunk of rows of one subject; LDS reduce; one fp32 atomic per column and
-// block into the zeroed output.
+// (one 16-B unit each) x 16 row lanes over ALL rows of one subject, then an LDS reduce over the row lanes: one writer per
+// output element and a fixed summation order, so the result is bit-reproducible (round 2 split the rows over several
+// blocks that met in fp32 atomics - run-to-run different sums).  A latency-sized op: Stage II reads 32 x 1153 rows.
 __global__ __launch_bounds__(256) void token_mean_kernel(const float* __restrict__ x, int64_t ld, int64_t N, int D,
-                                                         float* __restrict__ out, int64_t rows_per_blk, float inv_n) {
+                                                         float* __restrict__ out, float inv_n) {
   __shared__ float red[16][68];
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   const int c = (blockIdx.x * 16 + cl) * 4;
-  const int64_t b = blockIdx.z;
-  const int64_t r0 = (int64_t)blockIdx.y * rows_per_blk;
-  int64_t r1 = r0 + rows_per_blk; if (r1 > N) r1 = N;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int64_t b = blockIdx.y;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
   if (c < D) {     // ld is a multiple of 4 and columns [D, ld) are zero pads: the 16-B unit that straddles D is safe to read
     const float* base = x + b * N * ld + c;
-    for (int64_t r = r0 + rl; r < r1; r += 16) acc += *reinterpret_cast<const f32x4*>(base + r * ld);
+    int64_t r = rl;
+    for (; r + 16 < N; r += 32) {       // two independent loads in flight per thread
+      acc0 += *reinterpret_cast<const f32x4*>(base + r * ld);
+      acc1 += *reinterpret_cast<const f32x4*>(base + (r + 16) * ld);
+    }
+    if (r < N) acc0 += *reinterpret_cast<const f32x4*>(base + r * ld);
+    acc0 += acc1;
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) red[rl][cl * 4 + j] = acc[j];
+  for (int j = 0; j < 4; ++j) red[rl][cl * 4 + j] = acc0[j];
   __syncthreads();
   if (threadIdx.x < 64) {
     const int col = blockIdx.x * 64 + threadIdx.x;
@@ -135,21 +140,16 @@ __global__ __launch_bounds__(256) void token_mean_kernel(const float* __restrict
       float t = 0.f;
 #pragma unroll
       for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
-      atomicAdd(out + b * D + col, t * inv_n);
+      out[b * D + col] = t * inv_n;
     }
   }
 }
 extern "C" int vita_token_mean_fwd(const float* x, int64_t ld, int64_t B, int64_t N, int64_t D, float* out, void* stream) {
   VITA_REQUIRE(x && out && B > 0 && B < 65536 && N > 0 && D > 0 && ld % 4 == 0 && ld >= ((D + 3) / 4) * 4);
   VITA_REQUIRE(((uintptr_t)x & 15) == 0);
-  if (hipMemsetAsync(out, 0, (size_t)(B * D) * sizeof(float), (hipStream_t)stream) != hipSuccess) return VITA_ERR_LAUNCH;
   const int64_t colblk = (D + 63) / 64;
-  int64_t chunks = (2048 + colblk * B - 1) / (colblk * B);
-  if (chunks > (N + 63) / 64) chunks = (N + 63) / 64;
-  if (chunks < 1) chunks = 1;
-  const int64_t rpb = (N + chunks - 1) / chunks;
-  hipLaunchKernelGGL(token_mean_kernel, dim3((unsigned)colblk, (unsigned)chunks, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x,
-                     ld, N, (int)D, out, rpb, 1.0f / (float)N);
+  hipLaunchKernelGGL(token_mean_kernel, dim3((unsigned)colblk, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, ld, N, (int)D, out,
+                     1.0f / (float)N);
   VITA_CHECK_LAUNCH("vita_token_mean_fwd");
   return VITA_OK;
 }

@@ -3,6 +3,7 @@ sigmoid + MSE reconstruction criterion (utils/losses.py:92-140 'mse' branch on t
 utils/imaging_model_related.py:103-117)."""
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -13,18 +14,42 @@ from . import ops
 from .nn import _require_cuda
 
 
+def device_collectives(group) -> bool:
+    """True when the group's backend moves device memory itself (RCCL, torch's "nccl")."""
+    return "nccl" in str(dist.get_backend(group)).lower()
+
+
+def all_reduce_any(t: torch.Tensor, group):
+    """Blocking all-reduce(SUM) in place.  RCCL takes the device tensor.  Any other backend (gloo: CPU tests, and the
+    two-ranks-on-one-GPU test) only ever sees HOST memory: device tensors are staged - D2H on the current stream (which
+    orders the copy after the kernels that produced them, and blocks the host), the collective on the host copy, H2D.
+    gloo's own CUDA path (worker-thread stream syncs and pinned staging of its own) hung 1 run in 4 between two processes
+    sharing a GPU in round 2 (gpurun_out/r2_tests12.log: both ranks in finish() -> wait(), gloo worker without a Python
+    frame) and is therefore never used."""
+    if not t.is_cuda or device_collectives(group):
+        dist.all_reduce(t, group=group)
+        return t
+    h = t.detach().cpu()
+    dist.all_reduce(h, group=group)
+    t.detach().copy_(h)
+    return t
+
+
 def gather_towers(a: torch.Tensor, b: torch.Tensor, group):
     """All-gather both towers' [B_local, d] embeddings in ONE message -> ([B_global, d], [B_global, d]);
-    rank r's rows land at [r*B_local, (r+1)*B_local).  Device-agnostic (RCCL on GPU, gloo in CPU tests)."""
+    rank r's rows land at [r*B_local, (r+1)*B_local).  RCCL all_gather_into_tensor on device memory; other backends
+    (gloo) get host tensors (see all_reduce_any)."""
     world = dist.get_world_size(group)
     Bl, d = a.shape
     packed = torch.stack([a, b]).contiguous()
-    gathered = torch.empty(world, 2, Bl, d, dtype=a.dtype, device=a.device)
-    if hasattr(dist, "all_gather_into_tensor") and dist.get_backend(group) != "gloo":
+    if device_collectives(group):
+        gathered = torch.empty(world, 2, Bl, d, dtype=a.dtype, device=a.device)
         dist.all_gather_into_tensor(gathered, packed, group=group)
     else:
-        parts = list(gathered.unbind(0))
-        dist.all_gather(parts, packed, group=group)
+        hp = packed.detach().cpu()
+        parts = [torch.empty_like(hp) for _ in range(world)]
+        dist.all_gather(parts, hp, group=group)
+        gathered = torch.stack(parts).to(a.device)
     return (gathered[:, 0].reshape(world * Bl, d).contiguous(), gathered[:, 1].reshape(world * Bl, d).contiguous())
 
 
@@ -35,11 +60,11 @@ def scatter_tower_grads(cross: torch.Tensor, group):
     _, Bg, d = cross.shape
     Bl = Bg // world
     send = cross.view(2, world, Bl, d).permute(1, 0, 2, 3).contiguous()
-    if dist.get_backend(group) != "gloo":
+    if device_collectives(group):
         recv = torch.empty(2, Bl, d, dtype=cross.dtype, device=cross.device)
         dist.reduce_scatter_tensor(recv, send, group=group)
         return recv
-    dist.all_reduce(send, group=group)     # gloo has no reduce-scatter
+    all_reduce_any(send, group)            # gloo has no reduce-scatter; host-staged for device tensors
     return send[rank].contiguous()
 
 
@@ -93,14 +118,16 @@ class _ClipFn(torch.autograd.Function):
         out0 = out0.float().contiguous(); out1 = out1.float().contiguous()
         a, ia = ops.l2_normalize_fwd(out0)
         b, ib = ops.l2_normalize_fwd(out1)
+        # group is None = no exchange at all.  A group of ONE rank still runs every collective (CLIPLoss keeps such a
+        # group only when asked to: it is how the RCCL calls are exercised on a one-GPU box)
         world, rank = (dist.get_world_size(group), dist.get_rank(group)) if group is not None else (1, 0)
-        if world > 1:
+        if group is not None:
             a_all, b_all = gather_towers(a, b, group)
         else:
             a_all, b_all = a, b
         loss, l_it, _l_ti, d_it, d_ti, labels = clip_rank_forward(a, b, a_all, b_all, rank, tau, lam0)
-        if world > 1:
-            dist.all_reduce(loss, group=group)                           # report the global-batch loss
+        if group is not None:
+            all_reduce_any(loss, group)                                  # report the global-batch loss
         ctx.save_for_backward(a, b, ia, ib, a_all, b_all, d_it, d_ti)
         ctx.meta = (tau, group, world, grad_world_scale)
         ctx.mark_non_differentiable(l_it, labels)
@@ -110,7 +137,7 @@ class _ClipFn(torch.autograd.Function):
     def backward(ctx, gloss, _gl, _glab):
         a, b, ia, ib, a_all, b_all, d_it, d_ti = ctx.saved_tensors
         tau, group, world, gws = ctx.meta
-        if world > 1:
+        if group is not None:
             da, db, cross = clip_rank_backward(a, b, a_all, b_all, d_it, d_ti, tau)
             recv = scatter_tower_grads(cross, group)                      # backward of the all-gather
             da += recv[0]; db += recv[1]
@@ -128,10 +155,12 @@ class CLIPLoss(nn.Module):
     against the all-gathered other tower; the returned loss is the loss of the concatenated global
     batch, ``logits`` is [B_local, B_global] and ``labels = rank*B_local + arange(B_local)``.
     ``ddp_average=True`` pre-multiplies gradients by world_size so that DDP's 1/world averaging yields
-    exactly the gradient of the global-batch loss."""
+    exactly the gradient of the global-batch loss.  A group of one rank needs no exchange and is dropped, unless
+    ``collectives_at_world1=True`` (or VITA_CLIP_COLLECTIVES_AT_WORLD1=1): then the all-gather, the reduce-scatter
+    and the loss all-reduce run over that one rank as well - the same calls, shapes and dtypes as at world > 1."""
 
     def __init__(self, temperature: float, lambda_0: float = 0.5, gather_distributed: bool = False, group=None,
-                 ddp_average: bool = True) -> None:
+                 ddp_average: bool = True, collectives_at_world1: bool = False) -> None:
         super().__init__()
         self.temperature = temperature
         if lambda_0 > 1 or lambda_0 < 0:
@@ -141,6 +170,7 @@ class CLIPLoss(nn.Module):
         self.gather_distributed = gather_distributed
         self.group = group
         self.ddp_average = ddp_average
+        self.collectives_at_world1 = bool(collectives_at_world1)
 
     def forward(self, out0: torch.Tensor, out1: torch.Tensor) -> Tuple:
         _require_cuda(out0)
@@ -148,7 +178,9 @@ class CLIPLoss(nn.Module):
         if group is None and self.gather_distributed and dist.is_available() and dist.is_initialized():
             group = dist.group.WORLD
         world = dist.get_world_size(group) if group is not None else 1
-        return _ClipFn.apply(out0, out1, float(self.temperature), float(self.lambda_0), group if world > 1 else None,
+        keep1 = self.collectives_at_world1 or os.environ.get("VITA_CLIP_COLLECTIVES_AT_WORLD1") == "1"
+        return _ClipFn.apply(out0, out1, float(self.temperature), float(self.lambda_0),
+                             group if (world > 1 or keep1) else None,
                              float(world) if (self.ddp_average and world > 1) else 1.0)
 
 

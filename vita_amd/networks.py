@@ -11,6 +11,8 @@ attributes, return tuples and state_dict keys as the reference; the arithmetic r
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional
 
 import numpy as np
@@ -378,6 +380,9 @@ class ImagingMaskedDecoder(nn.Module):
 
 
 # ----------------------------------------------------------------------------- Stage II: tabular tower + heads
+CHECK_TABULAR_INPUT = os.environ.get("VITA_CHECK_TABULAR") == "1"
+
+
 class TabularViT(nn.Module):
     """Drop-in for networks/tabular_encoders.py:16-112: same constructor (args namespace + feature-name dict),
     parameter names (numerical_fe.i, single_c_fe.i, multi_c_fe.i, cls_token, enc_pos_embed, network.i, norm) and
@@ -433,6 +438,23 @@ class TabularViT(nn.Module):
             self._ncls = torch.tensor(ncls, dtype=torch.int32, device=dev)
         return self._wptr, self._bptr, self._ncls
 
+    def check_categorical_range(self, x):
+        """The reference's nn.Embedding raises IndexError on a categorical value outside [0, n_classes); the tokeniser
+        kernel clamps instead (memory safety) and would train silently on class 0 / n-1.  This host-side check (one
+        device sync; on with VITA_CHECK_TABULAR=1, or call it from a data-validation pass) restores the error, and also
+        rejects non-finite values, whose float -> int64 cast is undefined."""
+        if not torch.isfinite(x).all():
+            raise ValueError("vita_amd.TabularViT: non-finite tabular value")
+        ncls = [t.num_embeddings for t in self.single_c_fe] + [t.num_embeddings for t in self.multi_c_fe]
+        if ncls:
+            cat = x[:, self.num_numerical:self.num_features].long()
+            hi = torch.tensor(ncls, device=x.device)
+            bad = (cat < 0) | (cat >= hi)
+            if bad.any():
+                b, f = [int(v) for v in bad.nonzero()[0]]
+                raise IndexError(f"vita_amd.TabularViT: categorical feature {self.num_numerical + f} of row {b} has index "
+                                 f"{int(cat[b, f])}, out of range [0, {ncls[f]})")
+
     def forward_embeddings(self, x):
         """(B, n_features) -> (B, n_features, D), feature order numerical | single | multi (no cls, no pos-embed)."""
         _require_cuda(x)
@@ -440,6 +462,8 @@ class TabularViT(nn.Module):
 
     def _embed_padded(self, x, with_pos=True):
         ws, bs = self._feature_params()
+        if CHECK_TABULAR_INPUT:
+            self.check_categorical_range(x)
         return _mark(_TabEmbedFn.apply(x.float().contiguous(), self, with_pos, self.cls_token, *ws,
                                        *[b for b in bs if b is not None]))
 
@@ -550,12 +574,18 @@ class _HeadFn(torch.autograd.Function):
         h = torch.empty(B, Hd, dtype=torch.float32, device=dev)
         ops.sgemm(x, w0, h, B, Hd, Din, Din, Din, Hd)
         if bn.training or bn.running_mean is None:
+            if bn.training and B == 1:       # torch's BatchNorm1d raises too: the batch variance of one row is 0
+                raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(h.shape)}")
             track = bn.training and bn.track_running_stats and bn.running_mean is not None
-            a, mean, rstd = ops.batchnorm_fwd(h, gamma, beta, bn.eps, True, bn.running_mean if track else None,
-                                              bn.running_var if track else None,
-                                              bn.momentum if bn.momentum is not None else 0.1)
+            momentum = bn.momentum
             if track and bn.num_batches_tracked is not None:
                 bn.num_batches_tracked += 1
+                if momentum is None:         # torch: momentum=None = cumulative moving average, factor 1 / batches seen
+                    momentum = 1.0 / float(bn.num_batches_tracked.item())
+            if momentum is None:
+                momentum = 0.0
+            a, mean, rstd = ops.batchnorm_fwd(h, gamma, beta, bn.eps, True, bn.running_mean if track else None,
+                                              bn.running_var if track else None, momentum)
             ctx.train = True
         else:
             a = ops.batchnorm_eval(h, gamma, beta, bn.eps, True, bn.running_mean, bn.running_var)

@@ -102,9 +102,7 @@ def prefetch_shadows(device):
         return
     idx = device.index if device.index is not None else torch.cuda.current_device()
     main = torch.cuda.current_stream(idx)
-    side = _SIDE_STREAMS.get(idx)
-    if side is None:
-        side = _SIDE_STREAMS[idx] = _concurrent_stream(idx, main)
+    side = ensure_side_stream(device)
     side.wait_stream(main)          # after the optimizer step - and after every earlier use of the copies being replaced
     with torch.cuda.stream(side):
         for h in holders:
@@ -287,6 +285,24 @@ def _concurrent_stream(idx, main, tries=12, spin_us=200):
     return best[0]
 
 
+def ensure_side_stream(device, probe=True):
+    """The device's second stream, chosen (once) by the concurrency probe above.
+
+    The probe blocks the host on an event, so it must run where nothing else can be waiting for this thread: from the
+    constructors of FlatAdam / BucketedAllReduce and from the first Block FORWARD (main thread, no collective of the
+    step in flight yet) - never from a Block backward.  Round 2 probed lazily inside the first _BlockFn.backward, i.e.
+    on autograd's device thread after the reconstruction head's hooks could already have launched the first gradient
+    bucket: gpurun_out/r2_share2.log shows one rank blocked there (e1.synchronize) while its peer waited for it inside
+    the collective.  With probe=False (what a backward falls back to if no forward has run on this device) a plain
+    pool stream is taken without any host wait."""
+    idx = device.index if getattr(device, "index", None) is not None else torch.cuda.current_device()
+    s = _SIDE_STREAMS.get(idx)
+    if s is None:
+        s = _concurrent_stream(idx, torch.cuda.current_stream(idx)) if probe else torch.cuda.Stream(device=idx)
+        _SIDE_STREAMS[idx] = s
+    return s
+
+
 class _SideStream:
     """Weight / bias gradient launches of one Block backward on a second HIP stream.
 
@@ -306,9 +322,7 @@ class _SideStream:
         global _DEFERRED_DONE
         idx = device.index if device.index is not None else torch.cuda.current_device()
         self.main = torch.cuda.current_stream(idx)
-        self.side = _SIDE_STREAMS.get(idx)
-        if self.side is None:
-            self.side = _SIDE_STREAMS[idx] = _concurrent_stream(idx, self.main)
+        self.side = ensure_side_stream(device, probe=False)       # already chosen by the forward; never probes here
         self.prev = None          # Block backwards never nest; a list left behind by a failed backward is dropped
         _DEFERRED_DONE = []
 
@@ -389,6 +403,8 @@ class _BlockFn(torch.autograd.Function):
         dm: Dims = blk.dims
         B, N, Dp = xp.shape
         M = B * N
+        if WGRAD_SIDE_STREAM:
+            ensure_side_stream(xp.device)           # a dictionary hit after the first call (see its docstring)
         sh = blk.shadows()
         x = xp.reshape(M, Dp)
         ln1, mean1, rstd1 = ops.layernorm_fwd(x, Dp, n1w, n1b, M, dm.D, Dp, eps=blk.norm1.eps)

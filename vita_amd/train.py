@@ -12,9 +12,10 @@ import torch.distributed as dist
 from torch import nn
 
 from . import ops
-from .losses import CLIPLoss, recon_mse_from_logits
+from .losses import CLIPLoss, all_reduce_any, device_collectives, recon_mse_from_logits
 from .networks import ImagingMaskedDecoder, ImagingMaskedEncoder, SimCLRProjectionHead, TabularViT, token_mean
-from .nn import bump_shadow_epoch, prefetch_shadows
+from . import nn as _vnn
+from .nn import bump_shadow_epoch, ensure_side_stream, prefetch_shadows
 
 
 class ReconMAE(nn.Module):
@@ -111,6 +112,8 @@ class FlatAdam:
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.t = 0
         bump_shadow_epoch()
+        if dev.type == "cuda" and _vnn.WGRAD_SIDE_STREAM:
+            ensure_side_stream(dev)        # host-blocking stream probe: here, not in the first backward
 
     def zero_grad(self):
         self.g.zero_()
@@ -136,6 +139,17 @@ class BucketedAllReduce:
         self.opt, self.group = opt, group
         self.world = dist.get_world_size(group)
         self.cuda = opt.g.is_cuda
+        # RCCL reduces device memory asynchronously on its own stream.  Every other backend (gloo) gets host tensors:
+        # a bucket is staged through the host and reduced synchronously at its launch point (all_reduce_any)
+        self.async_device = self.cuda and device_collectives(group)
+        if self.cuda:
+            if self.async_device:
+                # create the communicator and RCCL's stream now (first step timing, and so that the stream-concurrency
+                # probe below sees every stream that will exist)
+                dist.all_reduce(torch.zeros(1, dtype=torch.float32, device=opt.g.device), group=group)
+            # the probe blocks the host: run it here, before any bucket can be in flight - never inside a backward
+            if _vnn.WGRAD_SIDE_STREAM:
+                ensure_side_stream(opt.g.device)
         cap = bucket_mb * (1 << 20) // 4
         self.buckets = []           # (start, end, n_params)
         self.bucket_of = {}
@@ -173,7 +187,10 @@ class BucketedAllReduce:
     def _launch(self, b):
         lo, hi, _ = self.buckets[b]
         self.launch_order.append(b)
-        self.handles.append(dist.all_reduce(self.opt.g[lo:hi], group=self.group, async_op=True))
+        if self.async_device or not self.cuda:
+            self.handles.append(dist.all_reduce(self.opt.g[lo:hi], group=self.group, async_op=True))
+        else:
+            all_reduce_any(self.opt.g[lo:hi], self.group)
 
     def finish(self):
         """Wait for every bucket (launching any whose hooks did not all fire) and reset."""
@@ -181,7 +198,7 @@ class BucketedAllReduce:
             if n != self.buckets[b][2]:
                 self._launch(b)
         for h in self.handles:
-            h.wait()                # CUDA: the current stream waits for the collective; gloo: the host does
+            h.wait()                # RCCL: the current stream waits for the collective; gloo (host tensors): the host does
         self.handles = []
         self.pending = [0] * len(self.buckets)
         self.fired = {}
