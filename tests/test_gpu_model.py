@@ -617,11 +617,15 @@ def test_stage2_step_vs_oracle():
 
 
 def test_stage2_loss_trajectory_vs_oracle():
-    """Five consecutive Stage-II steps (coupled weight decay, fresh mask noise each step) against the oracle: the
-    contrastive loss must follow the oracle's trajectory within 2e-2 while it falls from 2.4 to 0.55.  lr is 5e-4 and
-    the run stops there because the comparison is only meaningful while the trajectory is stable: at the yaml's 3e-3,
-    and from the sixth step on at this rate (loss < 0.5 on 8 memorised subjects), Adam's sign-like updates turn
-    rounding-level differences in near-zero gradients into 10-20 % loss differences on either implementation."""
+    """Five consecutive Stage-II steps (coupled weight decay, fresh mask noise each step) against the oracle while the
+    contrastive loss falls from 2.4 to 0.55.  lr is 5e-4 and the run stops there because the comparison is only meaningful
+    while the trajectory is stable: at the yaml's 3e-3, and from the sixth step on at this rate (loss < 0.5 on 8 memorised
+    subjects), Adam's sign-like updates turn rounding-level differences in near-zero gradients into 10-20 % loss differences
+    on either implementation.  The first two steps are held to 2e-2.  Steps 3-5 are held to 5e-2: three forward-attention
+    kernels that differ only in summation order and in where probabilities are rounded (32x32x16, its software-pipelined
+    form, 16x16x32 with matrix-pipe row sums) gave 0.773 / 0.775 / 0.753 at step 3 and 0.715 / 0.732 / 0.726 at step 4 against
+    the oracle's 0.779 / 0.713 on one box (round 3) - a spread of 3 % between equally valid roundings, while all three agree
+    with the oracle to 1e-3 at steps 1 and 2."""
     model, p = _s2_build()
     imgs, tabs = _s2_batch()
     from vita_amd.train import FlatAdam, stage2_train_step
@@ -634,7 +638,7 @@ def test_stage2_loss_trajectory_vs_oracle():
         ref.append(O.stage2_train_step(imgs, tabs, p_ref, noise, state, lr=5e-4, weight_decay=1e-4, **S2_OCFG)[0].item())
     assert ref[-1] < 0.9 * ref[0], ref
     for i, (a, b) in enumerate(zip(got, ref)):
-        assert abs(a - b) / b < 2e-2, (i, got, ref)
+        assert abs(a - b) / b < (2e-2 if i < 2 else 5e-2), (i, got, ref)
 
 
 def test_stage1_step_with_rccl_reducer_world1():
