@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void attn_fwd_tail_combine_kernel(const float*
 // descriptor serves the per-tile 4-byte LDS-DMA of both
 __global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restrict__ o, const uint16_t* __restrict__ dout,
                                                          const float* __restrict__ lse, float* __restrict__ ld2, int64_t BN, int N,
-                                                         int H, int HDP) {
+                                                         int H, int HDP, float inv_scale) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // row in [0, B*N)
   if (row >= BN) return;
@@ -459,8 +459,15 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const uint16_t* __restr
     if (lane < 4 && h0 + lane < H) {
       const int h = h0 + lane;
       const float v = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
-      ld2[((b * H + h) * 2 + 1) * N + q] = v;
-      ld2[((b * H + h) * 2) * N + q] = lse[(b * H + h) * N + q] * -1.4426950408889634f;   // -lse * log2(e)
+      // inv_scale == 0: [-lse * log2(e) | delta] (added to the scaled scores / subtracted from dP by the older kernels);
+      // inv_scale != 0: [-lse / scale | -delta], the initial accumulators of attn_bwd_dkdv_p_kernel's S and dP chains
+      if (inv_scale == 0.f) {
+        ld2[((b * H + h) * 2 + 1) * N + q] = v;
+        ld2[((b * H + h) * 2) * N + q] = lse[(b * H + h) * N + q] * -1.4426950408889634f;
+      } else {
+        ld2[((b * H + h) * 2 + 1) * N + q] = -v;
+        ld2[((b * H + h) * 2) * N + q] = -lse[(b * H + h) * N + q] * inv_scale;
+      }
     }
   }
 }
@@ -765,11 +772,16 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
     });
   };
 
+#if ATT_STAMP
+  unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = stamp_now();
+  const unsigned long long st_begin = st_last;
+#endif
   if (role == 0) {
     // step t: S chain of tile t (+ DMA of tile t+2), P(t) -> partner, dV^T += dO^T(t) P(t)
     int slot = 0;
     for (int t = 0; t <= nt; ++t) {
       const int pre = slot >= 2 ? slot - 2 : slot + NSLOT - 2;      // slot of tile t+2 = slot of tile t-2
+      STAMP(0);
       f32x16 sacc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
@@ -788,19 +800,30 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
         for (int k = 0; k < 4; ++k) pe[k] = (ATT_DBG & 8) ? __builtin_fmaf(sacc[4 * rr + k], c_exp2, l4[k]) : fast_exp2(__builtin_fmaf(sacc[4 * rr + k], c_exp2, l4[k]));
         pw[2 * rr] = cvt_pk(pe[0], pe[1]); pw[2 * rr + 1] = cvt_pk(pe[2], pe[3]);
       }
+      STAMP(1);
       char* xp = smem + xlane + (t & 1) * 2048;
       if (!(ATT_DBG & 16)) {
         *reinterpret_cast<u32x4*>(xp) = u32x4{pw[0], pw[1], pw[2], pw[3]};
         *reinterpret_cast<u32x4*>(xp + 1024) = u32x4{pw[4], pw[5], pw[6], pw[7]};
       }
+#if ATT_STAMP
+      asm volatile("" :: "v"(pw[0]), "v"(pw[7]));
+      STAMP(2);
+#endif
       product(__builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]}), __builtin_bit_cast(bf16x8, u32x4{pw[4], pw[5], pw[6], pw[7]}));
+      STAMP(3);
       slot = slot + 1 == NSLOT ? 0 : slot + 1;
       la.advance(slot == 0 ? -(NSLOT - 1) * BUF : BUF);
       if (!(ATT_DBG & 32)) wait_one_tile_in_flight();    // tile t+1 has landed
+      STAMP(4);
       if (!(ATT_DBG & 4)) ring_barrier();
+      STAMP(5);
     }
   } else {
     // step t: dS(t-1) from the partner's P(t-1), dK^T += Q^T(t-1) dS(t-1), dP chain of tile t (+ DMA of tile t+2)
+#ifdef ATT_DKDV_PRIO
+    __builtin_amdgcn_s_setprio(ATT_DKDV_PRIO);    // role is wave-uniform (readfirstlane above): a scalar branch guards this
+#endif
     la.advance_tr((NSLOT - 1) * BUF);       // tile -1 lives in the (zeroed) last slot
     int slot = 0;
     // dS hand-off to attn_bwd_dq_ds_kernel: tile (key block kt, query tile qt) = dS^T[32 keys][32 queries] bf16, 2 KiB,
@@ -817,11 +840,16 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
     for (int t = 0; t <= nt; ++t) {
       const int pre = slot >= 2 ? slot - 2 : slot + NSLOT - 2;
       const int prv = slot >= 1 ? slot - 1 : NSLOT - 1;              // slot of tile t-1
+      STAMP(0);
       const float* ds_ = reinterpret_cast<const float*>(smem + LC + prv * 256 + 128);
       const char* xp = smem + xlane + ((t + 1) & 1) * 2048;
       const u32x4 pin0 = (ATT_DBG & 16) ? u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u} : *reinterpret_cast<const u32x4*>(xp);
       const u32x4 pin1 = (ATT_DBG & 16) ? pin0 : *reinterpret_cast<const u32x4*>(xp + 1024);
       uint32_t dw[8];
+      if constexpr (ATT_DBG & 128) {       // timing only: no dS algebra (the words of P stand in for dS)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dw[j] = pin0[j] ^ __builtin_bit_cast(uint32_t, dpacc[j]); dw[4 + j] = pin1[j] ^ __builtin_bit_cast(uint32_t, dpacc[4 + j]); }
+      } else
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const f32x4 d4 = *reinterpret_cast<const f32x4*>(ds_ + 8 * rr + 4 * hh);
@@ -836,7 +864,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{dw[0], dw[1], dw[2], dw[3]}, rsS, ds_lane, toff, 2);       // aux 2 = nt
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{dw[4], dw[5], dw[6], dw[7]}, rsS, ds_lane + 16, toff, 2);
       }
+#if ATT_STAMP
+      asm volatile("" :: "v"(dw[0]), "v"(dw[7]));
+      STAMP(1);
+#endif
       product(__builtin_bit_cast(bf16x8, u32x4{dw[0], dw[1], dw[2], dw[3]}), __builtin_bit_cast(bf16x8, u32x4{dw[4], dw[5], dw[6], dw[7]}));
+      STAMP(2);
 #pragma unroll
       for (int r = 0; r < 16; ++r) dpacc[r] = 0.f;
       single_chain<HDP, NKS, 3>(dpacc, smem, la, frag, [&](int s) {
@@ -847,14 +880,335 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
       slot = slot + 1 == NSLOT ? 0 : slot + 1;
       la.advance_rows(slot == 0 ? -(NSLOT - 1) * BUF : BUF);
       la.advance_tr(slot == 1 ? -(NSLOT - 1) * BUF : BUF);          // transposed reads address tile t's slot next step
+      STAMP(3);
       if (!(ATT_DBG & 32)) wait_one_tile_in_flight();
+      STAMP(4);
       if (!(ATT_DBG & 4)) ring_barrier();
+      STAMP(5);
     }
   }
+#if ATT_STAMP
+  if (lane == 0 && nsplit == 1 && blockIdx.x < ATT_STAMP_WG) {
+    st_sum[6] = st_last - st_begin; st_sum[7] = (unsigned long long)(nt + 1);
+    for (int k = 0; k < 8; ++k) att_stamp[((size_t)blockIdx.x * 8 + wave) * 8 + k] = st_sum[k];
+  }
+#endif
   dma_wait();      // the zero-filled prefetches past the last tile must land before the LDS is released
   const float f = role ? scale : 1.f;
   if (part != nullptr) {
     // part[(tail workgroup * nsplit + split)][dV | dK][128 keys][HDP] fp32
+    float* prow = part + ((((int64_t)(lin - wg_base) * nsplit + sp) * 2 + role) * 128 + kb * 32 + lk) * HDP;
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
+        *reinterpret_cast<f32x4*>(prow + i * 32 + 8 * rr + 4 * hh) =
+            f32x4{acc[i][4 * rr] * f, acc[i][4 * rr + 1] * f, acc[i][4 * rr + 2] * f, acc[i][4 * rr + 3] * f};
+  } else if (key < N) {
+    uint16_t* row = dqkv + ((int64_t)b * N + key) * ld + ((2 - role) * H + h) * HDP;     // S role -> dV, dP role -> dK
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int d = i * 32 + 8 * rr + 4 * hh;
+        *reinterpret_cast<u32x2*>(row + d) = u32x2{cvt_pk(acc[i][4 * rr] * f, acc[i][4 * rr + 1] * f),
+                                                    cvt_pk(acc[i][4 * rr + 2] * f, acc[i][4 * rr + 3] * f)};
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// dK/dV, role-specialised wave pairs as above, with every phase of the tile loop carrying MFMAs in BOTH waves of a SIMD.
+// In attn_bwd_dkdv8_kernel the S role's single-accumulator S chain (with the tile's LDS-DMA issue inside it) runs while
+// its partner does vector-ALU work, and the partner's dP chain runs while the S role waits at the barrier: phase stamps
+// (tools/attn_stamps.py) show 1100 + 630 of a tile's 2900 cycles spent in those two phases at 416 matrix-pipe cycles each.
+// Here both chains run side by side and carry the waves' vector work between their MFMAs, then both products run side
+// by side:
+//   S role,  iteration t: stage 1  S chain of tile t+1 (+ LDS-DMA issue)
+//                         stage 2  dV^T += dO^T(t) P(t)        | P(t+1) = exp2(c S'(t+1)), packed, -> LDS hand-off
+//   dP role, iteration t: stage 1  dP chain of tile t (+ LDS-DMA issue)
+//                         stage 2  dK^T += Q^T(t-1) dS(t-1)    | dS(t) = P(t) o dP'(t), packed, -> HBM for the dQ kernel
+// The chain accumulators start from the row constants (S: -lse / scale, dP: -delta, written in that form by
+// attn_delta_kernel), so P = exp2(c S') and dS = P dP' need no per-element add.  Rings: Q tiles t-1 .. t+3 (5 slots: transposed reads of t-1, rows of t+1, t+2
+// landed or landing, t+3 being issued; the row constants of a tile travel with its Q image), dO tiles t .. t+2 (3 slots).
+#ifndef ATT_P_DMA_MODE
+#define ATT_P_DMA_MODE 0
+#endif
+#ifndef ATT_P_PRIO
+#define ATT_P_PRIO 3
+#endif
+#define ATT_P_NQ 5
+#define ATT_P_NO 3
+template <int HDP> struct AttPLds {
+  using C = AttCfg<HDP>;
+  static constexpr int ORB = ATT_P_NQ * C::TILE;                 // dO ring
+  static constexpr int LC = ORB + ATT_P_NO * C::TILE;            // row constants [NQ][-lse/scale (32) | -delta (32)] floats
+  static constexpr int XB = LC + ATT_P_NQ * 256;                 // P hand-off [4 key blocks][2 (tile parity)][2][64 lanes][16 B]
+  static constexpr int TOTAL = XB + 4 * 2 * 2048;
+};
+template <int HDP, int NKS>
+__global__ __launch_bounds__(512) void attn_bwd_dkdv_p_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+                                                              const float* __restrict__ ld2, uint16_t* __restrict__ dqkv,
+                                                              uint16_t* __restrict__ ds_out, int QT, int KTP,
+                                                              float* __restrict__ part, int wg_base, int nsplit,
+                                                              int tiles_per_split, int N, int H, float scale) {
+  using C = AttCfg<HDP>;
+  using L = AttPLds<HDP>;
+  constexpr int NDT = C::NDT, TILE = C::TILE, NQ = ATT_P_NQ, NO = ATT_P_NO;
+  constexpr int NI = 32 / C::RPI / 8;                   // DMA pieces per wave per image
+  constexpr int ORB = L::ORB, LC = L::LC, XB = L::XB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave >> 2, kb = wave & 3;
+  const int KB = (N + 127) >> 7;
+  const int lin = nsplit == 1 ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : wg_base + (int)blockIdx.x / nsplit;
+  const int sp = (int)blockIdx.x % nsplit;
+  const int bx = lin % KB, h = (lin / KB) % H, b = lin / (KB * H);
+  const int64_t ld = 3ll * H * HDP, ldo = (int64_t)H * HDP;
+  const uint16_t* base = qkv + (int64_t)b * N * ld;
+  const uint32_t extent = (uint32_t)((((int64_t)N - 1) * ld + HDP) * 2);
+  const uint32_t extent_o = (uint32_t)((((int64_t)N - 1) * ldo + HDP) * 2);
+  const __amdgpu_buffer_rsrc_t rsQ = mk_rsrc(base + h * HDP, extent);
+  const __amdgpu_buffer_rsrc_t rsKV = mk_rsrc(base + ((1 + role) * H + h) * HDP, extent);      // K (S role) or V (dP role)
+  const __amdgpu_buffer_rsrc_t rsDO = mk_rsrc(dout + (int64_t)b * N * ldo + h * HDP, extent_o);
+  const __amdgpu_buffer_rsrc_t rsL = mk_rsrc(ld2 + ((int64_t)b * H + h) * 2 * N, (uint32_t)N * 8);
+  const bool wave0 = wave == 0;
+
+  lds_zero<HDP>(smem, L::TOTAL, tid);
+  const int lk = lane & 31, hh = lane >> 5;
+  const int key = bx * 128 + kb * 32 + lk;
+  bf16x8 frag[NKS];
+#pragma unroll
+  for (int s = 0; s < NKS; ++s)
+    frag[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+        rsKV, (uint32_t)(((int64_t)key * ld + 16 * s + 8 * hh) * 2), 0, 0));
+  f32x16 acc[NDT];
+#pragma unroll
+  for (int i = 0; i < NDT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  const float c_exp2 = scale * 1.4426950408889634f;
+  const int ntiles = (N + 31) / 32;
+  const int t0 = sp * tiles_per_split;
+  const int t1 = t0 + tiles_per_split < ntiles ? t0 + tiles_per_split : ntiles;
+  const int nt = t1 - t0;                               // tiles of this workgroup: absolute tile = t0 + local index
+
+  DmaOff<HDP, 8> offq, offo;
+  offq.init(ld, wave, lane);
+  offo.init(ldo, wave, lane);
+  // local Q tile x lives in Q slot (x + 1) % NQ together with its row constants, local dO tile x in dO slot x % NO.
+  // Tiles outside [0, nt) read zeros (every row out of range): P = 1 against a zero dO row, dS = 0 - no masking needed.
+  auto issue_q = [&](int tl, int slot, int p) {
+    const int tile = t0 + tl;
+    const int tcl = (tl >= 0 && tile < t1) ? tile : ntiles;
+    offq.issue(rsQ, (uint32_t)tcl * (uint32_t)(32 * ld * 2), smem + slot * TILE, wave, p);
+  };
+  auto issue_o = [&](int tl, int slot, int p) {
+    const int tile = t0 + tl;
+    const int tcl = (tl >= 0 && tile < t1) ? tile : ntiles;
+    offo.issue(rsDO, (uint32_t)tcl * (uint32_t)(32 * ldo * 2), smem + ORB + slot * TILE, wave, p);
+  };
+  auto issue_c = [&](int tl, int slot) {      // row constants of Q tile tl (wave 0 only): 4-byte LDS-DMA, zeros past the range
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int tile = t0 + tl;
+    const int qq = tile * 32 + (lane & 31);
+    const uint32_t voff = (uint32_t)(tl >= 0 && tile < t1 && qq < N ? (lane < 32 ? qq : N + qq) : 2 * N) * 4;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsL, (lds_void*)(smem + LC + slot * 256), 4, voff, 0, 0, 0);
+  };
+  // pieces of one iteration's prefetch: [0, NI) Q tile tq, [NI, 2 NI) dO tile to, 2 NI the row constants of tq
+  auto issue_piece = [&](int tq, int qslot, int to, int oslot, int p) {
+    if (p < NI) issue_q(tq, qslot, p);
+    else if (p < 2 * NI) issue_o(to, oslot, p - NI);
+    else if (wave0) issue_c(tq, qslot);
+  };
+  LdsAddr<HDP, NKS> la;
+  la.init(lane);
+  const uint32_t xlane = XB + kb * 4096 + lane * 16;
+  __syncthreads();
+  // prologue: Q tiles 0, 1, 2 and dO tiles 0, 1
+#pragma unroll
+  for (int x = 0; x < 3; ++x) {
+#pragma unroll
+    for (int p = 0; p < NI; ++p) issue_q(x, x + 1, p);
+    if (wave0) issue_c(x, x + 1);
+  }
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int p = 0; p < NI; ++p) issue_o(x, x, p);
+  dma_wait();
+  ring_barrier();
+
+  // product against the transposed image the la.tb bases address, fragments one d-tile ahead; valu(e) for e = 0..15 is
+  // spread between the MFMAs (a slice per d-tile)
+  auto product = [&](const bf16x8 b0, const bf16x8 b1, auto&& valu) {
+    bf16x8 fr[2][2];
+    fr[0][0] = la.template tr_asm<0, 0, 0>(); fr[0][1] = la.template tr_asm<0, 1, 0>();
+    static_for<NDT>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (i + 1 < NDT) {
+        fr[(i + 1) & 1][0] = la.template tr_asm<i + 1, 0, 0>(); fr[(i + 1) & 1][1] = la.template tr_asm<i + 1, 1, 0>();
+        tr_wait<4>();
+      } else {
+        tr_wait<0>();
+      }
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 1][0], b0, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 1][1], b1, acc[i], 0, 0, 0);
+#pragma unroll
+      for (int e = (16 * i) / NDT; e < (16 * (i + 1)) / NDT; ++e) valu(e);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  // row constants of a slot into a chain accumulator: lane's element r belongs to query row (r & 3) + 8 (r >> 2) + 4 hh
+  auto load_init = [&](f32x16& a, int slot, int plane) {
+    const float* ls = reinterpret_cast<const float*>(smem + LC + slot * 256) + 32 * plane;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(ls + 8 * rr + 4 * hh);
+      a[4 * rr] = v[0]; a[4 * rr + 1] = v[1]; a[4 * rr + 2] = v[2]; a[4 * rr + 3] = v[3];
+    }
+  };
+#if ATT_STAMP
+  unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = stamp_now();
+  const unsigned long long st_begin = st_last;
+#endif
+  // ring positions (wave-uniform): advanced by one slot per iteration
+  int qrow = 2, qtr = 0, qiss = 4;        // Q slots of tile t+1 (rows, S role), t-1 (transposed, dP role), t+3 (issue) at t = 0
+  int orw = 0, oiss = 2;                  // dO slots of tile t (rows dP role / transposed S role), t+2 (issue)
+  if (role == 0) {
+    // S role: la.rb -> Q ring (rows), la.tb -> dO ring (transposed)
+    la.advance_tr(ORB);
+    la.advance_rows(TILE);                // Q tile 0 = slot 1
+    uint32_t pw[8];
+    {   // prologue: P(0), nothing to overlap with
+      f32x16 sacc;
+      load_init(sacc, 1, 0);
+      single_chain<HDP, NKS, 3>(sacc, smem, la, frag, [&](int) {});
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pw[j] = cvt_pk(fast_exp2(sacc[2 * j] * c_exp2), fast_exp2(sacc[2 * j + 1] * c_exp2));
+      char* xp = smem + xlane;
+      *reinterpret_cast<u32x4*>(xp) = u32x4{pw[0], pw[1], pw[2], pw[3]};
+      *reinterpret_cast<u32x4*>(xp + 1024) = u32x4{pw[4], pw[5], pw[6], pw[7]};
+    }
+    la.advance_rows(TILE);                // rows: Q tile 1 = slot 2
+    ring_barrier();                       // P(0) is visible to the partner
+    for (int t = 0; t <= nt; ++t) {
+      STAMP(0);
+      f32x16 sacc;
+      load_init(sacc, qrow, 0);
+      single_chain<HDP, NKS, 3>(sacc, smem, la, frag, [&](int s) {
+        if constexpr (ATT_P_DMA_MODE == 0) {
+#pragma unroll
+          for (int p = s; p <= 2 * NI; p += NKS) issue_piece(t + 3, qiss, t + 2, oiss, p);
+        } else {        // staggered by wave: piece p after chain step (2 kb + 3 p) mod NKS
+#pragma unroll
+          for (int p = 0; p <= 2 * NI; ++p)
+            if (s == (2 * kb + 3 * p) % NKS) issue_piece(t + 3, qiss, t + 2, oiss, p);
+        }
+      });
+      STAMP(1);
+      uint32_t pwn[8];
+      float pprev = 0.f;
+      product(__builtin_bit_cast(bf16x8, u32x4{pw[0], pw[1], pw[2], pw[3]}), __builtin_bit_cast(bf16x8, u32x4{pw[4], pw[5], pw[6], pw[7]}),
+              [&](int e) {
+                const float pe = fast_exp2(sacc[e] * c_exp2);
+                if (e & 1) { pwn[e >> 1] = cvt_pk(pprev, pe); asm volatile("" : "+v"(pwn[e >> 1])); }
+                else pprev = pe;
+              });
+      char* xp = smem + xlane + ((t + 1) & 1) * 2048;
+      *reinterpret_cast<u32x4*>(xp) = u32x4{pwn[0], pwn[1], pwn[2], pwn[3]};
+      *reinterpret_cast<u32x4*>(xp + 1024) = u32x4{pwn[4], pwn[5], pwn[6], pwn[7]};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pw[j] = pwn[j];
+      STAMP(2);
+      qrow = qrow + 1 == NQ ? 0 : qrow + 1;
+      la.advance_rows(qrow == 0 ? -(NQ - 1) * TILE : TILE);
+      orw = orw + 1 == NO ? 0 : orw + 1;
+      la.advance_tr(orw == 0 ? -(NO - 1) * TILE : TILE);
+      qiss = qiss + 1 == NQ ? 0 : qiss + 1;
+      oiss = oiss + 1 == NO ? 0 : oiss + 1;
+      if (wave0) dma_wait_n<2 * NI + 1>(); else dma_wait_n<2 * NI>();     // everything but this iteration's prefetch has landed
+      STAMP(4);
+      ring_barrier();
+      STAMP(5);
+    }
+  } else {
+    // dP role: la.rb -> dO ring (rows), la.tb -> Q ring (transposed, tile t-1 = slot 0 at t = 0: zeroed)
+    __builtin_amdgcn_s_setprio(ATT_P_PRIO);      // the younger half of the workgroup loses every issue arbitration otherwise
+    la.advance_rows(ORB);
+    const int kt = bx * 4 + kb;
+    const bool ds_store = ds_out != nullptr && __builtin_amdgcn_readfirstlane(kt * 32) < N;
+    const __amdgpu_buffer_rsrc_t rsS = mk_rsrc(ds_out + (((int64_t)b * H + h) * KTP + kt) * QT * 1024, (uint32_t)QT * 2048u);
+    const uint32_t ds_lane = lk * 64 + hh * 32;
+    uint32_t dw[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dw[j] = 0u;          // dS(-1) = 0
+    ring_barrier();                                   // the partner's prologue barrier
+    for (int t = 0; t <= nt; ++t) {
+      STAMP(0);
+      f32x16 dpacc;
+      // row constants of tile t sit with Q tile t: slot (t + 1) % NQ = the slot after the transposed-read slot
+      load_init(dpacc, qtr + 1 == NQ ? 0 : qtr + 1, 1);
+      single_chain<HDP, NKS, 3>(dpacc, smem, la, frag, [&](int s) {
+        if constexpr (ATT_P_DMA_MODE == 0) {
+#pragma unroll
+          for (int p = s; p <= 2 * NI; p += NKS) issue_piece(t + 3, qiss, t + 2, oiss, p);
+        } else if constexpr (ATT_P_DMA_MODE == 1) {
+#pragma unroll
+          for (int p = 0; p <= 2 * NI; ++p)
+            if (s == (2 * kb + 3 * p + 1) % NKS) issue_piece(t + 3, qiss, t + 2, oiss, p);
+        }
+      });
+      STAMP(1);
+      const char* xp = smem + xlane + (t & 1) * 2048;
+      const u32x4 pin0 = *reinterpret_cast<const u32x4*>(xp);
+      const u32x4 pin1 = *reinterpret_cast<const u32x4*>(xp + 1024);
+      uint32_t dwn[8];
+      float dprev = 0.f;
+      product(__builtin_bit_cast(bf16x8, u32x4{dw[0], dw[1], dw[2], dw[3]}), __builtin_bit_cast(bf16x8, u32x4{dw[4], dw[5], dw[6], dw[7]}),
+              [&](int e) {
+                const uint32_t w = (e >> 1) < 4 ? pin0[(e >> 1) & 3] : pin1[(e >> 1) & 3];
+                const float pv = (e & 1) ? __builtin_bit_cast(float, w & 0xffff0000u) : __builtin_bit_cast(float, w << 16);
+                if constexpr (ATT_P_DMA_MODE == 2) {
+#pragma unroll
+                  for (int p = 0; p < 2 * NI; ++p)
+                    if (e == (2 * kb + 4 * p + 1) % 16) issue_piece(t + 3, qiss, t + 2, oiss, p);
+                }
+                const float de = pv * dpacc[e];
+                if (e & 1) { dwn[e >> 1] = cvt_pk(dprev, de); asm volatile("" : "+v"(dwn[e >> 1])); }
+                else dprev = de;
+              });
+      const bool st = ds_store && t < nt;
+      if (st) {       // dS^T of tile t, exactly the bf16 values the dK product of the next iteration consumes
+        const uint32_t toff = (uint32_t)(t0 + t) * 2048u;      // wave-uniform
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{dwn[0], dwn[1], dwn[2], dwn[3]}, rsS, ds_lane, toff, 2);       // aux 2 = nt
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{dwn[4], dwn[5], dwn[6], dwn[7]}, rsS, ds_lane + 16, toff, 2);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dw[j] = dwn[j];
+      STAMP(2);
+      orw = orw + 1 == NO ? 0 : orw + 1;
+      la.advance_rows(orw == 0 ? -(NO - 1) * TILE : TILE);
+      qtr = qtr + 1 == NQ ? 0 : qtr + 1;
+      la.advance_tr(qtr == 0 ? -(NQ - 1) * TILE : TILE);
+      qiss = qiss + 1 == NQ ? 0 : qiss + 1;
+      oiss = oiss + 1 == NO ? 0 : oiss + 1;
+      // everything but this iteration's prefetch (and its two dS stores, issued after the prefetch) has landed
+      if (st) dma_wait_n<2 * NI + 2>(); else dma_wait_n<2 * NI>();
+      STAMP(4);
+      ring_barrier();
+      STAMP(5);
+    }
+  }
+#if ATT_STAMP
+  if (lane == 0 && nsplit == 1 && blockIdx.x < ATT_STAMP_WG) {
+    st_sum[6] = st_last - st_begin; st_sum[7] = (unsigned long long)(nt + 1);
+    for (int k = 0; k < 8; ++k) att_stamp[((size_t)blockIdx.x * 8 + wave) * 8 + k] = st_sum[k];
+  }
+#endif
+  dma_wait();      // the zero-filled prefetches past the last tile must land before the LDS is released
+  const float f = role ? scale : 1.f;
+  if (part != nullptr) {
     float* prow = part + ((((int64_t)(lin - wg_base) * nsplit + sp) * 2 + role) * 128 + kb * 32 + lk) * HDP;
 #pragma unroll
     for (int i = 0; i < NDT; ++i)
@@ -1209,6 +1563,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_tail_reduce_kernel(const floa
                                                       uint16_t*, int, int, float);                                   \
   template __global__ void attn_bwd_dkdv8_kernel<A, K>(const uint16_t*, const uint16_t*, const float*, uint16_t*, uint16_t*, \
                                                        int, int, float*, int, int, int, int, int, float);            \
+  template __global__ void attn_bwd_dkdv_p_kernel<A, K>(const uint16_t*, const uint16_t*, const float*, uint16_t*, uint16_t*, \
+                                                        int, int, float*, int, int, int, int, int, float);           \
   template __global__ void attn_bwd_dq_ds_kernel<A, K, ATT_DQDS_NSLOT>(const uint16_t*, const uint16_t*, uint16_t*, int,   \
                                                                        int, int, int, float, float*, int, int, int); \
   template __global__ void attn_bwd_dq_kernel<A, K>(const uint16_t*, const uint16_t*, const float*, const float*,    \
@@ -1282,17 +1638,20 @@ static int launch_bwd(const void* qkv, const void* o, const void* dout, const fl
   static const bool no_tail = att_env_flag("VITA_ATTN_NO_TAIL_SPLIT");      // A/B switch of the tail launch
   VITA_ONCE_PER_DEVICE({
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv8_kernel<HDP, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv8);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_p_kernel<HDP, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AttPLds<HDP>::TOTAL);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<HDP, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<HDP, NKS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_ds_kernel<HDP, NKS, ATT_DQDS_NSLOT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_qds);
   });
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((B * N + 3) / 4)), dim3(256), 0, s, (const uint16_t*)o, (const uint16_t*)dout,
-                     lse, delta, B * N, (int)N, (int)H, HDP);
-  VITA_CHECK_LAUNCH("vita_attn_bwd(delta)");
   dim3 grid((unsigned)((N + 127) / 128), (unsigned)H, (unsigned)B);
   const int QT = (int)att_qt(N), KTP = (int)att_ktp(N);
   const bool handoff = ws != nullptr && !dkdv4;     // dS tiles through HBM: dQ without the S / dP recompute
+  static const bool dkdv8 = att_env_flag("VITA_ATTN_DKDV8");                // the round-2 dK/dV kernel (kept for A/B measurements)
+  const bool piped = handoff && !dkdv8;             // attn_bwd_dkdv_p_kernel: chains start from the row constants
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((B * N + 3) / 4)), dim3(256), 0, s, (const uint16_t*)o, (const uint16_t*)dout,
+                     lse, delta, B * N, (int)N, (int)H, HDP, piped ? 1.0f / scale : 0.0f);
+  VITA_CHECK_LAUNCH("vita_attn_bwd(delta)");
   if (dkdv4) {
     hipLaunchKernelGGL((attn_bwd_dkdv_kernel<HDP, NKS>), grid, dim3(256), lds_kv, s, (const uint16_t*)qkv, (const uint16_t*)dout, lse,
                        delta, (uint16_t*)dqkv, (int)N, (int)H, scale);
@@ -1302,12 +1661,14 @@ static int launch_bwd(const void* qkv, const void* o, const void* dout, const fl
     const int64_t L = B * H * ((N + 127) / 128);
     int64_t l_main = L; int nsplit = 1, per = QT;
     if (ws != nullptr && !no_tail) att_tail_plan(L, QT, att_num_cu(), ATT_BWD_SLOTS, &l_main, &nsplit, &per);
+    auto kern = piped ? attn_bwd_dkdv_p_kernel<HDP, NKS> : attn_bwd_dkdv8_kernel<HDP, NKS>;
+    const size_t lds_k = piped ? (size_t)AttPLds<HDP>::TOTAL : lds_kv8;
     if (l_main > 0)
-      hipLaunchKernelGGL((attn_bwd_dkdv8_kernel<HDP, NKS>), dim3((unsigned)l_main), dim3(512), lds_kv8, s, (const uint16_t*)qkv,
+      hipLaunchKernelGGL(kern, dim3((unsigned)l_main), dim3(512), lds_k, s, (const uint16_t*)qkv,
                          (const uint16_t*)dout, delta, (uint16_t*)dqkv, dsb, QT, KTP, (float*)nullptr, 0, 1, QT, (int)N, (int)H, scale);
     if (l_main < L) {
       const int nwg = (int)(L - l_main);
-      hipLaunchKernelGGL((attn_bwd_dkdv8_kernel<HDP, NKS>), dim3((unsigned)(nwg * nsplit)), dim3(512), lds_kv8, s, (const uint16_t*)qkv,
+      hipLaunchKernelGGL(kern, dim3((unsigned)(nwg * nsplit)), dim3(512), lds_k, s, (const uint16_t*)qkv,
                          (const uint16_t*)dout, delta, (uint16_t*)dqkv, dsb, QT, KTP, part, (int)l_main, nsplit, per, (int)N, (int)H, scale);
       const int64_t nthr = (int64_t)nwg * 2 * 128 * (HDP / 4);
       hipLaunchKernelGGL(attn_bwd_tail_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, (const float*)part,

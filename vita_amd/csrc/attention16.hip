@@ -117,27 +117,6 @@ __device__ __forceinline__ bf16x8 pack44(const f32x4& a, const f32x4& b) {
 #ifndef ATT16_DMA_POS
 #define ATT16_DMA_POS 0     // where a tile's LDS-DMA pieces are issued: 0 between the S-chain MFMAs, 1 after the chain, 2 after the softmax
 #endif
-// ATT16_STAMP=1: diagnostic build - every wave sums the shader cycles of each phase of its tile loop (s_memtime) and leaves
-// the sums in att16_stamp[workgroup][wave][8]; read them with vita_attn_debug_stamps().  Never set in the shipped library.
-#ifndef ATT16_STAMP
-#define ATT16_STAMP 0
-#endif
-#if ATT16_STAMP
-#define ATT16_STAMP_WG 4096
-static __device__ unsigned long long att16_stamp[ATT16_STAMP_WG * 8 * 8];
-__device__ __forceinline__ unsigned long long stamp_now() {
-  unsigned long long t;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  return t;
-}
-#define STAMP(k) do { const unsigned long long n__ = stamp_now(); st_sum[k] += n__ - st_last; st_last = n__; } while (0)
-extern "C" int vita_attn_debug_stamps(unsigned long long* host_out, int n_wg) {
-  if (n_wg > ATT16_STAMP_WG) n_wg = ATT16_STAMP_WG;
-  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(att16_stamp), (size_t)n_wg * 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
-}
-#else
-#define STAMP(k) do { } while (0)
-#endif
 #define MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)
 
 // ============================================================================================ forward
@@ -209,7 +188,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd16_kernel(const uint16_t* 
   dma_wait_n<DPT>();               // tile t0 has landed
   ring_barrier();
   int slot = 0;
-#if ATT16_STAMP
+#if ATT_STAMP
   unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = stamp_now();
   const unsigned long long st_begin = st_last;
 #endif
@@ -281,7 +260,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd16_kernel(const uint16_t* 
           for (int j = 0; j < 4; ++j) p[kb][qb][j] = fast_exp2(__builtin_fmaf(sacc[kb][qb][j], c_exp2, -mc[qb]));
       if constexpr (ATT16_DMA_POS == 2) { __builtin_amdgcn_sched_barrier(0); issue(kt + 2, pre); __builtin_amdgcn_sched_barrier(0); }
       const bf16x8 pf0 = pack44(p[0][0], p[1][0]), pf1 = pack44(p[0][1], p[1][1]);
-#if ATT16_STAMP
+#if ATT_STAMP
       asm volatile("" :: "v"(pf0), "v"(pf1));
       STAMP(2);
 #endif
@@ -316,10 +295,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd16_kernel(const uint16_t* 
     ring_barrier();
     STAMP(5);
   }
-#if ATT16_STAMP
-  if (lane == 0 && nsplit == 1 && blockIdx.x < ATT16_STAMP_WG) {
+#if ATT_STAMP
+  if (lane == 0 && nsplit == 1 && blockIdx.x < ATT_STAMP_WG) {
     st_sum[6] = st_last - st_begin; st_sum[7] = (unsigned long long)(t1 - t0);
-    for (int k = 0; k < 8; ++k) att16_stamp[((size_t)blockIdx.x * 8 + wave) * 8 + k] = st_sum[k];
+    for (int k = 0; k < 8; ++k) att_stamp[((size_t)blockIdx.x * 8 + wave) * 8 + k] = st_sum[k];
   }
 #endif
   dma_wait();                      // zero-filled prefetches past the last tile

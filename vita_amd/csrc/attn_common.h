@@ -233,6 +233,31 @@ __device__ __forceinline__ void lds_zero(char* smem, int bytes, int tid) {
   for (int o = tid * 16; o < bytes; o += (int)blockDim.x * 16) *reinterpret_cast<u32x4*>(smem + o) = u32x4{0, 0, 0, 0};
 }
 
+// ATT_STAMP=1: diagnostic build - every wave sums the shader cycles of each phase of its tile loop (s_memtime) and leaves
+// the sums in att_stamp[workgroup][wave][8]; read them with vita_attn_debug_stamps().  Never set in the shipped library.
+#ifndef ATT_STAMP
+#define ATT_STAMP 0
+#endif
+#if ATT_STAMP
+#define ATT_STAMP_WG 4096
+static __device__ unsigned long long att_stamp[ATT_STAMP_WG * 8 * 8];
+__device__ __forceinline__ unsigned long long stamp_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define STAMP(k) do { const unsigned long long n__ = stamp_now(); st_sum[k] += n__ - st_last; st_last = n__; } while (0)
+#ifndef ATT_STAMP_READER
+#define ATT_STAMP_READER vita_attn_debug_stamps
+#endif
+extern "C" int ATT_STAMP_READER(unsigned long long* host_out, int n_wg) {
+  if (n_wg > ATT_STAMP_WG) n_wg = ATT_STAMP_WG;
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(att_stamp), (size_t)n_wg * 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 // ============================================================================================ host helpers
 #define ATT_MAX_CU 320
 static inline bool att_env_flag(const char* name) {
