@@ -186,214 +186,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_kernel(const uint16_t* __
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// The same forward, software-pipelined inside every wave.  Both waves of a SIMD run this program in step (one barrier per
-// tile), so in attn_fwd_kernel they reach the softmax together and the matrix pipe idles for that whole vector-ALU phase
-// (counters: MFMA-busy 54-59 %, a wave spends 37 % of its cycles stalled at issue and 29 % in s_waitcnt / the barrier).
-// Here every phase of the loop carries MFMAs:
-//   stage A: S chain of tile t+1 (MFMA + K row reads + LDS-DMA of tile t+3) | the pending O rescale, when a row maximum moved
-//   stage B: O^T += V^T P^T of tile t (MFMA + transposed V reads)          | softmax of tile t+1, a slice per d-tile
-// so one wave's exp / max / pack work issues in the gaps of its own (and its partner's) MFMAs.  Ring of 4 slots
-// [K image | V image]: tile t (V reads), t+1 (K reads), t+2 (landed or landing), t+3 (being issued).
-#define ATT_FWDP_NSLOT 4
-template <int HDP, int NKS, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_pipe_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ o,
-                                                                   float* __restrict__ lse, float* __restrict__ part, int wg_base,
-                                                                   int nsplit, int tiles_per_split, int N, int H, float c_exp2) {
-  using C = AttCfg<HDP>;
-  constexpr int RS = C::RS, NDT = C::NDT, BUF = 2 * C::TILE, NSLOT = ATT_FWDP_NSLOT;
-  constexpr int DPT = 2 * (32 / C::RPI / NW);                   // DMA instructions per wave per tile
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int QB = (N + NW * 32 - 1) / (NW * 32);
-  const int lin = nsplit == 1 ? xcd_contiguous((int)blockIdx.x, (int)gridDim.x) : wg_base + (int)blockIdx.x / nsplit;
-  const int sp = (int)blockIdx.x % nsplit;
-  const int bx = lin % QB, h = (lin / QB) % H, b = lin / (QB * H);
-  const int64_t ld = 3ll * H * HDP;
-  const int q0 = bx * (NW * 32) + wave * 32;
-  const uint16_t* base = qkv + (int64_t)b * N * ld;
-  const uint32_t extent = (uint32_t)((((int64_t)N - 1) * ld + HDP) * 2);
-  const __amdgpu_buffer_rsrc_t rsQ = mk_rsrc(base + h * HDP, extent);
-  const __amdgpu_buffer_rsrc_t rsK = mk_rsrc(base + (H + h) * HDP, extent);
-  const __amdgpu_buffer_rsrc_t rsV = mk_rsrc(base + (2 * H + h) * HDP, extent);
-
-  lds_zero<HDP>(smem, NSLOT * BUF, tid);
-  const int lq = lane & 31, hh = lane >> 5;
-  const bool active = __builtin_amdgcn_readfirstlane(q0) < N;     // waves past the last row only feed the ring
-  bf16x8 qf[NKS];
-#pragma unroll
-  for (int s = 0; s < NKS; ++s)
-    qf[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-        rsQ, (uint32_t)((((int64_t)q0 + lq) * ld + 16 * s + 8 * hh) * 2), 0, 0));
-  f32x16 oacc[NDT];
-#pragma unroll
-  for (int i = 0; i < NDT; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-
-  const int ntiles = (N + 31) / 32;
-  const int t0 = sp * tiles_per_split;
-  const int t1 = t0 + tiles_per_split < ntiles ? t0 + tiles_per_split : ntiles;
-  LdsAddr<HDP, NKS> la;
-  la.init(lane);
-  constexpr int NI = 32 / C::RPI / NW;      // DMA pieces per wave per image
-  DmaOff<HDP, NW> off;
-  off.init(ld, wave, lane);
-  auto issue_piece = [&](int tile, int buf, int p) {
-    const int tcl = tile < t1 ? tile : ntiles;             // tiles past the range read zeros (and are masked below)
-    const uint32_t toff = (uint32_t)tcl * (uint32_t)(32 * ld * 2);
-    if (p < NI) off.issue(rsK, toff, smem + buf * BUF, wave, p);
-    else off.issue(rsV, toff, smem + buf * BUF + C::TILE, wave, p - NI);
-  };
-  auto issue = [&](int tile, int buf) {
-#pragma unroll
-    for (int p = 0; p < 2 * NI; ++p) issue_piece(tile, buf, p);
-  };
-  // scores of keys outside this workgroup's range: past N, or a tile at / past t1 (the prefetch reads zeros there)
-  auto mask_tile = [&](f32x16& sacc, int tile) {
-    if (tile >= t1) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[r] = -INFINITY;
-    } else if (tile * 32 + 32 > N) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        if (tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= N) sacc[r] = -INFINITY;
-    }
-  };
-  // softmax of one tile in 18 units (0: row maximum and rescale factor, 1..16: one score each, 17: running sum), so that
-  // the units can be spread over the MFMAs of a concurrent product
-  float mc = 0.f, alpha = 1.f, rs = 0.f, pe_prev = 0.f;
-  bool moved = false;
-  uint32_t pwn[8];
-  auto softmax_unit = [&](int u, const f32x16& sacc) {
-    if (u == 0) {
-      float mx = sacc[0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      mc = m_new * c_exp2;
-      moved = __any(m_new > m_run);      // exact: the O rescale is skipped only when no row's maximum moved
-      alpha = fast_exp2((m_run - m_new) * c_exp2);
-      m_run = m_new;
-      rs = 0.f;
-    } else if (u <= 16) {
-      const int e = u - 1;
-      const float pe = fast_exp2(__builtin_fmaf(sacc[e], c_exp2, -mc));
-      rs += pe;
-      if (e & 1) {
-        pwn[e >> 1] = cvt_pk(pe_prev, pe);
-        asm volatile("" : "+v"(pwn[e >> 1]));     // keep the unit where it is written: between the MFMAs
-      } else {
-        pe_prev = pe;
-      }
-    } else {
-      l_run = __builtin_fmaf(l_run, alpha, rs);
-    }
-  };
-  __syncthreads();
-  issue(t0, 0); issue(t0 + 1, 1); issue(t0 + 2, 2);
-  dma_wait_n<2 * DPT>();           // tile t0 has landed
-  ring_barrier();
-  bf16x8 pf0, pf1;
-  {   // prologue: scores and softmax of tile t0, nothing to overlap with
-    f32x16 sacc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-    if (active) {
-      single_chain<HDP, NKS, 4>(sacc, smem, la, qf, [&](int) {});
-      mask_tile(sacc, t0);
-#pragma unroll
-      for (int u = 0; u < 18; ++u) softmax_unit(u, sacc);
-    }
-    pf0 = __builtin_bit_cast(bf16x8, u32x4{pwn[0], pwn[1], pwn[2], pwn[3]});
-    pf1 = __builtin_bit_cast(bf16x8, u32x4{pwn[4], pwn[5], pwn[6], pwn[7]});
-    moved = false;                 // O is still zero
-  }
-  la.advance_rows(BUF);            // row reads address tile t0+1's slot, transposed reads tile t0's
-  dma_wait_n<DPT>();               // tile t0+1 has landed
-  ring_barrier();
-  int slot = 0;                    // slot of tile kt
-  for (int kt = t0; kt < t1; ++kt) {
-    const int pre = slot >= 1 ? slot - 1 : NSLOT - 1;     // slot of tile kt+3 = slot of tile kt-1
-    if (active) {
-      // ---- stage A
-      if (moved) {
-#pragma unroll
-        for (int i = 0; i < NDT; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-      }
-      f32x16 sacc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-      single_chain<HDP, NKS, 3>(sacc, smem, la, qf, [&](int s) {
-#pragma unroll
-        for (int p = s; p < 2 * NI; p += NKS) issue_piece(kt + 3, pre, p);
-      });
-      mask_tile(sacc, kt + 1);
-      // ---- stage B: transposed V fragments one d-tile ahead of their MFMAs, softmax units of tile kt+1 between them
-      {
-        bf16x8 fr[2][2];
-        fr[0][0] = la.template tr_asm<0, 0, C::TILE>(); fr[0][1] = la.template tr_asm<0, 1, C::TILE>();
-        static_for<NDT>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          if constexpr (i + 1 < NDT) {
-            fr[(i + 1) & 1][0] = la.template tr_asm<i + 1, 0, C::TILE>(); fr[(i + 1) & 1][1] = la.template tr_asm<i + 1, 1, C::TILE>();
-            tr_wait<4>();
-          } else {
-            tr_wait<0>();
-          }
-          oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 1][0], pf0, oacc[i], 0, 0, 0);
-          oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 1][1], pf1, oacc[i], 0, 0, 0);
-#pragma unroll
-          for (int u = (18 * i) / NDT; u < (18 * (i + 1)) / NDT; ++u) softmax_unit(u, sacc);
-          __builtin_amdgcn_sched_barrier(0);
-        });
-      }
-      pf0 = __builtin_bit_cast(bf16x8, u32x4{pwn[0], pwn[1], pwn[2], pwn[3]});
-      pf1 = __builtin_bit_cast(bf16x8, u32x4{pwn[4], pwn[5], pwn[6], pwn[7]});
-    } else {
-      issue(kt + 3, pre);          // waves past the last query row only feed the ring
-    }
-    slot = slot + 1 == NSLOT ? 0 : slot + 1;
-    la.advance_tr(slot == 0 ? -(NSLOT - 1) * BUF : BUF);
-    la.advance_rows(slot == NSLOT - 1 ? -(NSLOT - 1) * BUF : BUF);   // rows address slot+1
-    dma_wait_n<DPT>();             // tile kt+2 has landed
-    ring_barrier();
-  }
-  dma_wait();                      // zero-filled prefetches past the last tile
-  // the softmax of the tile past the range ran last: every score was masked, so it left m_run, l_run and O untouched
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.f / l_tot;
-  const int q = q0 + lq;
-  if (part != nullptr) {
-    float* pw_ = part + ((int64_t)(lin - wg_base) * nsplit + sp) * ((NW * 32) * (HDP + 1));
-    if (active) {
-      float* prow = pw_ + (int64_t)(wave * 32 + lq) * HDP;
-#pragma unroll
-      for (int i = 0; i < NDT; ++i)
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
-          *reinterpret_cast<f32x4*>(prow + i * 32 + 8 * rr + 4 * hh) =
-              f32x4{oacc[i][4 * rr] * inv, oacc[i][4 * rr + 1] * inv, oacc[i][4 * rr + 2] * inv, oacc[i][4 * rr + 3] * inv};
-      if (hh == 0) pw_[(NW * 32) * HDP + wave * 32 + lq] = m_run * c_exp2 + log2f(l_tot);
-    }
-  } else if (q < N) {
-    uint16_t* orow = o + ((int64_t)b * N + q) * ((int64_t)H * HDP) + h * HDP;
-#pragma unroll
-    for (int i = 0; i < NDT; ++i)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int d = i * 32 + 8 * rr + 4 * hh;
-        *reinterpret_cast<u32x2*>(orow + d) = u32x2{cvt_pk(oacc[i][4 * rr] * inv, oacc[i][4 * rr + 1] * inv),
-                                                     cvt_pk(oacc[i][4 * rr + 2] * inv, oacc[i][4 * rr + 3] * inv)};
-      }
-    if (hh == 0) lse[((int64_t)b * H + h) * N + q] = (m_run * c_exp2 + log2f(l_tot)) * 0.6931471805599453f;
-  }
-}
-
 // merge the key ranges of the tail workgroups: o = sum_s o_s 2^(l_s - L), L = log2 sum_s 2^l_s (fixed order)
 __global__ __launch_bounds__(256) void attn_fwd_tail_combine_kernel(const float* __restrict__ part, uint16_t* __restrict__ o,
                                                                     float* __restrict__ lse, int wg_base, int nwg, int nsplit,
@@ -931,9 +723,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
 // The chain accumulators start from the row constants (S: -lse / scale, dP: -delta, written in that form by
 // attn_delta_kernel), so P = exp2(c S') and dS = P dP' need no per-element add.  Rings: Q tiles t-1 .. t+3 (5 slots: transposed reads of t-1, rows of t+1, t+2
 // landed or landing, t+3 being issued; the row constants of a tile travel with its Q image), dO tiles t .. t+2 (3 slots).
-#ifndef ATT_P_DMA_MODE
-#define ATT_P_DMA_MODE 0
-#endif
 #ifndef ATT_P_PRIO
 #define ATT_P_PRIO 3
 #endif
@@ -1097,14 +886,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_p_kernel(const uint16_t* __
       f32x16 sacc;
       load_init(sacc, qrow, 0);
       single_chain<HDP, NKS, 3>(sacc, smem, la, frag, [&](int s) {
-        if constexpr (ATT_P_DMA_MODE == 0) {
 #pragma unroll
-          for (int p = s; p <= 2 * NI; p += NKS) issue_piece(t + 3, qiss, t + 2, oiss, p);
-        } else {        // staggered by wave: piece p after chain step (2 kb + 3 p) mod NKS
-#pragma unroll
-          for (int p = 0; p <= 2 * NI; ++p)
-            if (s == (2 * kb + 3 * p) % NKS) issue_piece(t + 3, qiss, t + 2, oiss, p);
-        }
+        for (int p = s; p <= 2 * NI; p += NKS) issue_piece(t + 3, qiss, t + 2, oiss, p);
       });
       STAMP(1);
       uint32_t pwn[8];
@@ -1150,14 +933,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_p_kernel(const uint16_t* __
       // row constants of tile t sit with Q tile t: slot (t + 1) % NQ = the slot after the transposed-read slot
       load_init(dpacc, qtr + 1 == NQ ? 0 : qtr + 1, 1);
       single_chain<HDP, NKS, 3>(dpacc, smem, la, frag, [&](int s) {
-        if constexpr (ATT_P_DMA_MODE == 0) {
 #pragma unroll
-          for (int p = s; p <= 2 * NI; p += NKS) issue_piece(t + 3, qiss, t + 2, oiss, p);
-        } else if constexpr (ATT_P_DMA_MODE == 1) {
-#pragma unroll
-          for (int p = 0; p <= 2 * NI; ++p)
-            if (s == (2 * kb + 3 * p + 1) % NKS) issue_piece(t + 3, qiss, t + 2, oiss, p);
-        }
+        for (int p = s; p <= 2 * NI; p += NKS) issue_piece(t + 3, qiss, t + 2, oiss, p);
       });
       STAMP(1);
       const char* xp = smem + xlane + (t & 1) * 2048;
@@ -1169,11 +946,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_p_kernel(const uint16_t* __
               [&](int e) {
                 const uint32_t w = (e >> 1) < 4 ? pin0[(e >> 1) & 3] : pin1[(e >> 1) & 3];
                 const float pv = (e & 1) ? __builtin_bit_cast(float, w & 0xffff0000u) : __builtin_bit_cast(float, w << 16);
-                if constexpr (ATT_P_DMA_MODE == 2) {
-#pragma unroll
-                  for (int p = 0; p < 2 * NI; ++p)
-                    if (e == (2 * kb + 4 * p + 1) % 16) issue_piece(t + 3, qiss, t + 2, oiss, p);
-                }
                 const float de = pv * dpacc[e];
                 if (e & 1) { dwn[e >> 1] = cvt_pk(dprev, de); asm volatile("" : "+v"(dwn[e >> 1])); }
                 else dprev = de;
@@ -1569,10 +1341,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_tail_reduce_kernel(const floa
                                                                        int, int, int, float, float*, int, int, int); \
   template __global__ void attn_bwd_dq_kernel<A, K>(const uint16_t*, const uint16_t*, const float*, const float*,    \
                                                     uint16_t*, int, int, float);
-template __global__ void attn_fwd_pipe_kernel<224, 13, 8>(const uint16_t*, uint16_t*, float*, float*, int, int, int, int, int, float);
-template __global__ void attn_fwd_pipe_kernel<64, 3, 8>(const uint16_t*, uint16_t*, float*, float*, int, int, int, int, int, float);
-template __global__ void attn_fwd_pipe_kernel<32, 2, 8>(const uint16_t*, uint16_t*, float*, float*, int, int, int, int, int, float);
-template __global__ void attn_fwd_pipe_kernel<128, 8, 8>(const uint16_t*, uint16_t*, float*, float*, int, int, int, int, int, float);
 template __global__ void attn_fwd_kernel<224, 13, 8>(const uint16_t*, uint16_t*, float*, float*, int, int, int, int, int, float);
 template __global__ void attn_fwd_kernel<64, 3, 8>(const uint16_t*, uint16_t*, float*, float*, int, int, int, int, int, float);
 template __global__ void attn_fwd_kernel<32, 2, 8>(const uint16_t*, uint16_t*, float*, float*, int, int, int, int, int, float);
@@ -1596,13 +1364,9 @@ template <int HDP, int NKS>
 static int launch_fwd(const void* qkv, void* o, float* lse, void* ws, int64_t B, int64_t N, int64_t H, float scale, hipStream_t s) {
   constexpr int NW = 8;
   static const bool no_tail = att_env_flag("VITA_ATTN_NO_TAIL_SPLIT");    // A/B switch of the tail launch
-  static const bool nopipe = att_env_flag("VITA_ATTN_FWD_NOPIPE");        // A/B switch: the forward without in-wave software pipelining
-  const size_t lds = (nopipe ? ATT_NSLOT : ATT_FWDP_NSLOT) * 2 * AttCfg<HDP>::TILE;
-  VITA_ONCE_PER_DEVICE({
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HDP, NKS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ATT_NSLOT * 2 * AttCfg<HDP>::TILE));
-    (void)hipFuncSetAttribute((const void*)attn_fwd_pipe_kernel<HDP, NKS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ATT_FWDP_NSLOT * 2 * AttCfg<HDP>::TILE));
-  });
-  auto kern = nopipe ? attn_fwd_kernel<HDP, NKS, NW> : attn_fwd_pipe_kernel<HDP, NKS, NW>;
+  const size_t lds = ATT_NSLOT * 2 * AttCfg<HDP>::TILE;
+  VITA_ONCE_PER_DEVICE((void)hipFuncSetAttribute((const void*)attn_fwd_kernel<HDP, NKS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  auto kern = attn_fwd_kernel<HDP, NKS, NW>;
   const int64_t L = B * H * ((N + NW * 32 - 1) / (NW * 32));
   const int ntiles = (int)((N + 31) / 32);
   int64_t l_main = L; int nsplit = 1, per = ntiles;

@@ -114,9 +114,6 @@ __device__ __forceinline__ bf16x8 pack44(const f32x4& a, const f32x4& b) {
 #ifndef ATT16_THR
 #define ATT16_THR 8.0f      // see the lazy reference maximum in attn_fwd16_kernel
 #endif
-#ifndef ATT16_DMA_POS
-#define ATT16_DMA_POS 0     // where a tile's LDS-DMA pieces are issued: 0 between the S-chain MFMAs, 1 after the chain, 2 after the softmax
-#endif
 #define MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)
 
 // ============================================================================================ forward
@@ -213,14 +210,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd16_kernel(const uint16_t* 
           sacc[i & 1][0] = MFMA16(a[i % DEPTH], qf[0][i >> 1], sacc[i & 1][0]);
           sacc[i & 1][1] = MFMA16(a[i % DEPTH], qf[1][i >> 1], sacc[i & 1][1]);
           if (i + DEPTH < NA) a[i % DEPTH] = la.row(smem, (i + DEPTH) >> 1, (i + DEPTH) & 1);
-          if constexpr (ATT16_DMA_POS == 0) {
 #pragma unroll
-            for (int p = i; p < 2 * NI; p += NA) issue_piece(kt + 2, pre, p);
-          }
+          for (int p = i; p < 2 * NI; p += NA) issue_piece(kt + 2, pre, p);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (ATT16_DMA_POS == 1) { issue(kt + 2, pre); __builtin_amdgcn_sched_barrier(0); }
       STAMP(1);
       if (kbase + 32 > N) {
 #pragma unroll
@@ -258,7 +252,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd16_kernel(const uint16_t* 
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
           for (int j = 0; j < 4; ++j) p[kb][qb][j] = fast_exp2(__builtin_fmaf(sacc[kb][qb][j], c_exp2, -mc[qb]));
-      if constexpr (ATT16_DMA_POS == 2) { __builtin_amdgcn_sched_barrier(0); issue(kt + 2, pre); __builtin_amdgcn_sched_barrier(0); }
       const bf16x8 pf0 = pack44(p[0][0], p[1][0]), pf1 = pack44(p[0][1], p[1][1]);
 #if ATT_STAMP
       asm volatile("" :: "v"(pf0), "v"(pf1));
@@ -349,21 +342,22 @@ template __global__ void attn_fwd16_kernel<128, 8, 8>(const uint16_t*, uint16_t*
 template <int HDP, int ND>
 static int launch_fwd16(const void* qkv, void* o, float* lse, void* ws, int64_t B, int64_t N, int64_t H, float scale, hipStream_t s) {
   constexpr int NW = 8;
-  const size_t lds = ATT_NSLOT * 2 * AttCfg<HDP>::TILE;
   static const bool no_tail = att_env_flag("VITA_ATTN_NO_TAIL_SPLIT");
+  const size_t lds = ATT_NSLOT * 2 * AttCfg<HDP>::TILE;
   const void* fn = (const void*)attn_fwd16_kernel<HDP, ND, NW>;
   VITA_ONCE_PER_DEVICE((void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  auto kern = attn_fwd16_kernel<HDP, ND, NW>;
   const int64_t L = B * H * ((N + NW * 32 - 1) / (NW * 32));
   const int ntiles = (int)((N + 31) / 32);
   int64_t l_main = L; int nsplit = 1, per = ntiles;
   if (ws != nullptr && !no_tail) att_tail_plan(L, ntiles, att_num_cu(), ATT_FWD_SLOTS, &l_main, &nsplit, &per);
   const float c = scale * 1.4426950408889634f;
   if (l_main > 0)
-    hipLaunchKernelGGL((attn_fwd16_kernel<HDP, ND, NW>), dim3((unsigned)l_main), dim3(NW * 64), lds, s, (const uint16_t*)qkv,
+    hipLaunchKernelGGL(kern, dim3((unsigned)l_main), dim3(NW * 64), lds, s, (const uint16_t*)qkv,
                        (uint16_t*)o, lse, (float*)nullptr, 0, 1, ntiles, (int)N, (int)H, c);
   if (l_main < L) {
     const int nwg = (int)(L - l_main);
-    hipLaunchKernelGGL((attn_fwd16_kernel<HDP, ND, NW>), dim3((unsigned)(nwg * nsplit)), dim3(NW * 64), lds, s, (const uint16_t*)qkv,
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nwg * nsplit)), dim3(NW * 64), lds, s, (const uint16_t*)qkv,
                        (uint16_t*)o, lse, (float*)ws, (int)l_main, nsplit, per, (int)N, (int)H, c);
     att_launch_fwd_combine((const float*)ws, o, lse, (int)l_main, nwg, nsplit, (int)N, (int)H, HDP, NW * 32, s);
   }
