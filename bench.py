@@ -165,9 +165,10 @@ def dry_run(args):
 
 
 # rocprofv3 kernel names behind each timed launch group of vita_amd.ops (for roofline.traffic)
-GROUP_KERNELS = {"attn_bwd_kernels": ("attn_delta_kernel", "attn_bwd_dkdv_kernel", "attn_bwd_dkdv8_kernel", "attn_bwd_dq_kernel",
-                                      "attn_bwd_dq_ds_kernel", "attn_bwd_tail_reduce_kernel", "attn_bwd_dq_tail_reduce_kernel"),
-                 "attn_fwd_kernel": ("attn_fwd_kernel",)}
+GROUP_KERNELS = {"attn_bwd_kernels": ("attn_delta_kernel", "attn_bwd_dkdv_kernel", "attn_bwd_dkdv8_kernel", "attn_bwd_dkdv_p_kernel",
+                                      "attn_bwd_dq_kernel", "attn_bwd_dq_ds_kernel", "attn_bwd_tail_reduce_kernel",
+                                      "attn_bwd_dq_tail_reduce_kernel"),
+                 "attn_fwd_kernel": ("attn_fwd_kernel", "attn_fwd16_kernel", "attn_fwd_tail_combine_kernel")}
 
 
 def pmc_traffic(group, frames, batch, launches_per_step):
