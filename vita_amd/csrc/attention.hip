@@ -887,7 +887,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_p_kernel(const uint16_t* __
       load_init(sacc, qrow, 0);
       single_chain<HDP, NKS, 3>(sacc, smem, la, frag, [&](int s) {
 #pragma unroll
-        for (int p = s; p <= 2 * NI; p += NKS) issue_piece(t + 3, qiss, t + 2, oiss, p);
+        for (int p = s; p <= 2 * NI; p += NKS) if (!(ATT_DBG & 256) || !(t & 1)) issue_piece(t + 3, qiss, t + 2, oiss, p);   // 256: timing only, half the Q / dO stream
       });
       STAMP(1);
       uint32_t pwn[8];
@@ -934,7 +934,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_p_kernel(const uint16_t* __
       load_init(dpacc, qtr + 1 == NQ ? 0 : qtr + 1, 1);
       single_chain<HDP, NKS, 3>(dpacc, smem, la, frag, [&](int s) {
 #pragma unroll
-        for (int p = s; p <= 2 * NI; p += NKS) issue_piece(t + 3, qiss, t + 2, oiss, p);
+        for (int p = s; p <= 2 * NI; p += NKS) if (!(ATT_DBG & 256) || !(t & 1)) issue_piece(t + 3, qiss, t + 2, oiss, p);   // 256: timing only, half the Q / dO stream
       });
       STAMP(1);
       const char* xp = smem + xlane + (t & 1) * 2048;
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_p_kernel(const uint16_t* __
                 if (e & 1) { dwn[e >> 1] = cvt_pk(dprev, de); asm volatile("" : "+v"(dwn[e >> 1])); }
                 else dprev = de;
               });
-      const bool st = ds_store && t < nt;
+      const bool st = ds_store && t < nt && !(ATT_DBG & 1);      // 1: timing only, no dS stores
       if (st) {       // dS^T of tile t, exactly the bf16 values the dK product of the next iteration consumes
         const uint32_t toff = (uint32_t)(t0 + t) * 2048u;      // wave-uniform
         __builtin_amdgcn_raw_buffer_store_b128(u32x4{dwn[0], dwn[1], dwn[2], dwn[3]}, rsS, ds_lane, toff, 2);       // aux 2 = nt
