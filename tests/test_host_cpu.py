@@ -168,3 +168,32 @@ def test_load_pretrained_weights_prefix_filter(tmp_path):
     kept = filter_state_dict(ref, ["decoder_imaging"], ["decoder_imaging.dec_pos_embed"])
     assert kept and all(k.startswith("decoder_imaging") and "dec_pos_embed" not in k for k in kept)
     assert filter_state_dict(ref) == dict(ref)
+
+
+def test_bench_traffic_lookup_knows_the_profiled_kernels():
+    """roofline.traffic comes from the newest committed PMC summary: every attention kernel in it must belong to one of
+    bench.py's launch groups (a renamed kernel otherwise drops out of the sum silently), and the dominant group's
+    traffic must at least cover its algorithmic bytes."""
+    import glob
+    import importlib.util
+    import json
+    import subprocess
+    spec = importlib.util.spec_from_file_location("vita_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True)
+    t50 = [f for f in newest if json.load(open(f)).get("frames") == 50 and json.load(open(f)).get("per_gpu_batch") == 2]
+    assert t50, "no T=50 traffic summary under profiles/"
+    kernels = json.load(open(t50[0]))["kernels"]
+    grouped = [n for names in bench.GROUP_KERNELS.values() for n in names]
+    for k in kernels:
+        if "attn_" in k:
+            assert any(k.startswith(n) or (" " + n) in k for n in grouped), k
+    # every grouped kernel name exists in the library (a stale name in GROUP_KERNELS is dead weight, a typo is a bug)
+    syms = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "vita_amd", "libvita_hip.so")],
+                          capture_output=True, text=True).stdout
+    for n in grouped:
+        assert n in syms, n
+    traffic, src = bench.pmc_traffic("attn_bwd_kernels", 50, 2, 8)
+    assert traffic is not None and src == os.path.basename(t50[0])
+    # Q, K, V, O, dO in and dQ, dK, dV out of the smaller (encoder) launch: B=2, N=6913, H=5, hdp=224, bf16
+    assert traffic > 8 * 2 * 6913 * 5 * 224 * 2
