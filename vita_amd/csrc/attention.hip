@@ -841,8 +841,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_p_kernel(const uint16_t* __
       } else {
         tr_wait<0>();
       }
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 1][0], b0, acc[i], 0, 0, 0);
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i & 1][1], b1, acc[i], 0, 0, 0);
+      acc[i] = mfma32_or_proxy(fr[i & 1][0], b0, acc[i]);
+      acc[i] = mfma32_or_proxy(fr[i & 1][1], b1, acc[i]);
 #pragma unroll
       for (int e = (16 * i) / NDT; e < (16 * (i + 1)) / NDT; ++e) valu(e);
       __builtin_amdgcn_sched_barrier(0);

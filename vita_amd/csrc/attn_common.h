@@ -8,7 +8,8 @@
 
 // Timing-only dissection builds of the dK/dV kernel (tools/attn_dissect.sh; results are INVALID when non-zero):
 // 1 = no dS stores, 2 = no in-loop LDS-DMA issue, 4 = no per-tile barrier, 8 = no exp, 16 = no P hand-off through LDS,
-// 32 = no in-loop wait for tile arrival, 64 = LDS operand reads of the chains cut to the first 3 (rows) / 4 (transposed)
+// 32 = no in-loop wait for tile arrival, 64 = LDS operand reads of the chains cut to the first 3 (rows) / 4 (transposed),
+// 256 = Q / dO LDS-DMA for every other tile only, 512 = two 16x16x32 MFMAs in place of each 32x32x16 (see mfma32_or_proxy)
 #ifndef ATT_DBG
 #define ATT_DBG 0
 #endif
@@ -151,6 +152,22 @@ __device__ __forceinline__ void dual_chain(f32x16& acc0, f32x16& acc1, const cha
 }
 
 
+// ATT_DBG & 512 (timing only, results INVALID): every 32x32x16 MFMA of the dK/dV tile loop replaced by two 16x16x32 MFMAs on
+// the same operand registers - the same FLOPs, operand reads and issue slots a 16x16x32 re-tiling would have - to price
+// that re-tiling before building it.
+__device__ __forceinline__ f32x16 mfma32_or_proxy(const bf16x8 a, const bf16x8 b, f32x16 acc) {
+  if constexpr (ATT_DBG & 512) {
+    f32x4 lo = {acc[0], acc[1], acc[2], acc[3]}, hi = {acc[4], acc[5], acc[6], acc[7]};
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, lo, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, hi, 0, 0, 0);
+    acc[0] = lo[0]; acc[1] = lo[1]; acc[2] = lo[2]; acc[3] = lo[3];
+    acc[4] = hi[0]; acc[5] = hi[1]; acc[6] = hi[2]; acc[7] = hi[3];
+    return acc;
+  } else {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+  }
+}
+
 template <int HDP, int NKS, int DEPTH, class F>
 __device__ __forceinline__ void single_chain(f32x16& acc, const char* img, const LdsAddr<HDP, NKS>& la, const bf16x8 (&b)[NKS],
                                              F&& between) {
@@ -160,7 +177,7 @@ __device__ __forceinline__ void single_chain(f32x16& acc, const char* img, const
 #pragma unroll
   for (int s = 0; s < NKS; ++s) {
     __builtin_amdgcn_sched_barrier(0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % DEPTH], b[s], acc, 0, 0, 0);
+    acc = mfma32_or_proxy(a[s % DEPTH], b[s], acc);
     if (s + DEPTH < NKS && !(ATT_DBG & 64)) a[s % DEPTH] = la.row(img, s + DEPTH);
     between(s);
   }
