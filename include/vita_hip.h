@@ -113,6 +113,13 @@ int vita_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype, const flo
                        const float* dx_in, float* dx_out, int64_t lddx, void* dx_bf16,
                        int64_t ld_dxb, float* dgamma, float* dbeta, float* partial, int64_t rows,
                        int64_t d, void* stream);
+/* vita_layernorm_bwd with the row sums ADDED to dgamma / dbeta (one writer per element, no atomics): what autograd's
+ * `weight.grad += dgamma` does for norm1 / norm2 (networks/imaging_encoders.py:41,115) without the extra launches. */
+int vita_layernorm_bwd_acc(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx,
+                           const float* gamma, const float* mean, const float* rstd,
+                           const float* dx_in, float* dx_out, int64_t lddx, void* dx_bf16,
+                           int64_t ld_dxb, float* dgamma, float* dbeta, float* partial, int64_t rows,
+                           int64_t d, void* stream);
 
 /* vita_layernorm_bwd for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results (bit-identical: the

@@ -270,7 +270,7 @@ def test_block_backward_side_stream_matches_single_stream():
         reported = []
         try:
             for p in blk.parameters():
-                p.grad = torch.zeros_like(p) if inplace else None
+                p.grad = torch.full_like(p, 0.5) if inplace else None       # non-zero: in place means ADDED to what is there
                 if inplace:
                     vnn.GRAD_READY[id(p)] = lambda q: reported.append(id(q))
             xg = x.clone().requires_grad_(True)
@@ -286,9 +286,9 @@ def test_block_backward_side_stream_matches_single_stream():
         g1, dx1, rep = run(True, inplace)
         assert torch.equal(dx0, dx1)
         for k in g0:
-            assert rel(g1[k], g0[k]) < 1e-5, (k, inplace)
-        if inplace:      # the eight Linear weights / biases minus the qkv bias (returned through autograd)
-            want = {id(p) for n, p in blk.named_parameters() if "norm" not in n and n != "attn.qkv.bias"}
+            assert rel(g1[k] - (0.5 if inplace else 0.0), g0[k]) < 1e-5, (k, inplace)
+        if inplace:      # everything but the qkv bias (returned through autograd): Linear weights / biases, LayerNorm weights / biases
+            want = {id(p) for n, p in blk.named_parameters() if n != "attn.qkv.bias"}
             assert want <= set(rep)
     assert vnn._DEFERRED_DONE is None
 

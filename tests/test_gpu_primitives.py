@@ -132,6 +132,12 @@ def test_layernorm(ops, rows, d):
     torch.testing.assert_close(dxb.cpu().float(), dx.cpu(), rtol=1e-2, atol=1e-2)
     torch.testing.assert_close(dg.cpu(), gr.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(db.cpu(), br.grad, rtol=1e-4, atol=1e-4)
+    # accumulating form (vita_layernorm_bwd_acc): the same sums, bit for bit, ADDED to what the buffers hold
+    accg = torch.full((d,), 0.25, device="cuda"); accb = torch.full((d,), -1.5, device="cuda")
+    dx2, _, none_g, none_b = ops.layernorm_bwd(dev(dy), ld, dev(x), ld, dev(g), mean, rstd, rows, d, ld, dx_in=dev(dxin),
+                                               want_bf16=True, ld_dxb=ld, acc=(accg, accb))
+    assert none_g is None and none_b is None and torch.equal(dx2, dx)
+    assert torch.equal(accg, 0.25 + dg) and torch.equal(accb, -1.5 + db)
 
 
 def test_argsort_mask_bit_exact(ops, golden):

@@ -42,6 +42,7 @@ SIGNATURES = {
     "vita_layernorm_fwd": [vp, i64, vp, vp, vp, i64, i32, vp, vp, i64, i64, f32, vp],
     "vita_layernorm_bwd_nblk": [i64],
     "vita_layernorm_bwd": [vp, i64, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, i64, vp],
+    "vita_layernorm_bwd_acc": [vp, i64, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, vp, i64, i64, vp],
     "vita_layernorm_bwd_noalloc": [vp, i64, i32, vp, i64, vp, vp, vp, vp, vp, i64, vp, i64, vp, vp, i64, i64, vp],
     "vita_argsort_mask": [vp, i64, i64, i64, vp, vp, vp, vp],
     "vita_row_gather_f32": [vp, i64, i64, vp, i64, vp, vp, vp, i64, i64, i64, i64, vp],

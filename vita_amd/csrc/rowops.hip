@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 3) void ln_bwd_kernel(const void* __restrict__
 // grid (ceil(d/64), 2): blockIdx.y = 0 sums the dgamma partials, 1 the dbeta partials; 16 waves take interleaved
 // partial rows with four independent accumulators each (the 2 x nblk x d fp32 partials are L2-resident)
 __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __restrict__ partial, int nblk, int d, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta) {
+                                                             float* __restrict__ dbeta, int acc) {
   __shared__ float red[16][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cx;
@@ -248,13 +248,15 @@ __global__ __launch_bounds__(1024) void ln_bwd_reduce_kernel(const float* __rest
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < 16; ++w) t += red[w][cx];
-    (blockIdx.y ? dbeta : dgamma)[c] = t;
+    float* o = (blockIdx.y ? dbeta : dgamma) + c;      // one writer per element: accumulating stays deterministic
+    *o = acc ? *o + t : t;
   }
 }
 
 static int ln_bwd_impl(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx, const float* gamma,
                        const float* mean, const float* rstd, const float* dx_in, float* dx_out, int64_t lddx, void* dx_bf16,
-                       int64_t ld_dxb, float* dgamma, float* dbeta, float* partial, int64_t rows, int64_t d, void* stream) {
+                       int64_t ld_dxb, float* dgamma, float* dbeta, float* partial, int64_t rows, int64_t d, void* stream,
+                       bool acc = false) {
   VITA_REQUIRE(dy && x && gamma && mean && rstd && dx_out && dgamma && dbeta && partial);
   VITA_REQUIRE(rows > 0 && d > 0 && d <= LN_MAXV * 256 && lddx <= LN_MAXV * 256);
   VITA_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && lddx >= d && ldx >= ((d + 3) / 4) * 4 && lddy >= ((d + 3) / 4) * 4);
@@ -272,7 +274,7 @@ static int ln_bwd_impl(const void* dy, int64_t lddy, int32_t dy_dtype, const flo
 #undef LN_BWD_LAUNCH
   VITA_CHECK_LAUNCH("vita_layernorm_bwd");
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((d + 63) / 64), 2), dim3(1024), 0, (hipStream_t)stream, partial,
-                     nblk, (int)d, dgamma, dbeta);
+                     nblk, (int)d, dgamma, dbeta, acc ? 1 : 0);
   VITA_CHECK_LAUNCH("vita_layernorm_bwd_reduce");
   return VITA_OK;
 }
@@ -282,6 +284,14 @@ extern "C" int vita_layernorm_bwd(const void* dy, int64_t lddy, int32_t dy_dtype
                                   float* dbeta, float* partial, int64_t rows, int64_t d, void* stream) {
   return ln_bwd_impl(dy, lddy, dy_dtype, x, ldx, gamma, mean, rstd, dx_in, dx_out, lddx, dx_bf16, ld_dxb, dgamma, dbeta, partial,
                      rows, d, stream);
+}
+// the same, with the row sums ADDED to dgamma / dbeta (gradients accumulated straight into an optimizer's buffer)
+extern "C" int vita_layernorm_bwd_acc(const void* dy, int64_t lddy, int32_t dy_dtype, const float* x, int64_t ldx,
+                                      const float* gamma, const float* mean, const float* rstd, const float* dx_in,
+                                      float* dx_out, int64_t lddx, void* dx_bf16, int64_t ld_dxb, float* dgamma,
+                                      float* dbeta, float* partial, int64_t rows, int64_t d, void* stream) {
+  return ln_bwd_impl(dy, lddy, dy_dtype, x, ldx, gamma, mean, rstd, dx_in, dx_out, lddx, dx_bf16, ld_dxb, dgamma, dbeta, partial,
+                     rows, d, stream, true);
 }
 
 // The same backward for callers that cannot allocate: the dgamma / dbeta partials ([2][nblk][d] fp32, every element the

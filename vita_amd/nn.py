@@ -237,6 +237,18 @@ def grad_target(param):
 _DEFERRED_DONE = None         # list while a Block backward has launches in flight on its side stream
 
 
+LN_INPLACE_GRADS = os.environ.get("VITA_LN_INPLACE", "1") != "0"
+
+
+def ln_grad_targets(ln, need_w, need_b):
+    """(weight.grad, bias.grad) of a LayerNorm when BOTH can take their gradient in place (vita_layernorm_bwd_acc), else None:
+    autograd's `grad += dgamma` is a 5 us launch plus a launch gap per vector on the main stream, four per Block."""
+    if not (need_w and need_b and LN_INPLACE_GRADS):
+        return None
+    gw, gb = grad_target(ln.weight), grad_target(ln.bias)
+    return (gw, gb) if gw is not None and gb is not None else None
+
+
 def grad_done(param):
     """After an in-place accumulation: run the hook autograd would have run (bucketed all-reduce bookkeeping).
     While a side stream holds the accumulating launches the report waits for the join (_SideStream.join)."""
@@ -459,8 +471,11 @@ class _BlockFn(torch.autograd.Function):
         ops.gemm(du, sh["fc1_w"], dln2, M, Dp, dm.Hp, dm.Hp, Dp, Dp, b_layout=1, flops=2.0 * M * D * dm.hidden)
         if not side.on:
             del du
+        acc2 = ln_grad_targets(blk.norm2, need[8], need[9])
         dx1, dx1b, d_n2w, d_n2b = ops.layernorm_bwd(dln2, Dp, x1, Dp, n2w, mean2, rstd2, M, D, Dp, dx_in=dx2,
-                                                    want_bf16=True, ld_dxb=Dp)
+                                                    want_bf16=True, ld_dxb=Dp, acc=acc2)
+        if acc2 is not None:
+            grad_done(blk.norm2.weight); grad_done(blk.norm2.bias)
         # ---- attention
         d_projw = side(wgrad, dx1b, Dp, o, dm.AO, D, D, M, col_seg=(dm.hdp, dm.hd), n_phys=dm.AO, param=a.proj.weight) \
             if need[6] else None
@@ -475,8 +490,11 @@ class _BlockFn(torch.autograd.Function):
             d_qkvb = side(lambda: ops.unpack_vec(ops.colsum(dqkv, dm.QKV, M, dm.QKV), 3 * D, seg=(dm.hdp, dm.hd)))
         dln1 = torch.empty(M, Dp, dtype=torch.bfloat16, device=x.device)
         ops.gemm(dqkv, sh["qkv_w"], dln1, M, Dp, dm.QKV, dm.QKV, Dp, Dp, b_layout=1, flops=6.0 * M * D * D)
+        acc1 = ln_grad_targets(blk.norm1, need[2], need[3])
         dx, dxb, d_n1w, d_n1b = ops.layernorm_bwd(dln1, Dp, x, Dp, n1w, mean1, rstd1, M, D, Dp, dx_in=dx1, want_bf16=True,
-                                                  ld_dxb=Dp)
+                                                  ld_dxb=Dp, acc=acc1)
+        if acc1 is not None:
+            grad_done(blk.norm1.weight); grad_done(blk.norm1.bias)
         side.join()
         dx = with_bf16_twin(dx.view(B, N, Dp), dxb)
         return (dx, None, d_n1w, d_n1b, d_qkvw, d_qkvb, d_projw, d_projb, d_n2w, d_n2b, d_fc1w, d_fc1b,
@@ -549,12 +567,13 @@ def _require_cuda(x):
 # ----------------------------------------------------------------------------- LayerNorm / Linear on the padded stream
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xp, w, b, eps, D):
+    def forward(ctx, xp, w, b, eps, D, ln):
         B, N, Dp = xp.shape
         x = xp.reshape(B * N, Dp)
         y, mean, rstd = ops.layernorm_fwd(x, Dp, w, b, B * N, D, Dp, out_dtype=torch.float32, eps=eps)
         ctx.save_for_backward(x, w, mean, rstd)
         ctx.D = D
+        ctx.ln = ln
         return y.view(B, N, Dp)
 
     @staticmethod
@@ -562,12 +581,15 @@ class _LayerNormFn(torch.autograd.Function):
         x, w, mean, rstd = ctx.saved_tensors
         B, N, Dp = dy.shape
         dy = dy.contiguous().view(B * N, Dp)
-        dx, dxb, dw, db = ops.layernorm_bwd(dy, Dp, x, Dp, w, mean, rstd, B * N, ctx.D, Dp, want_bf16=True, ld_dxb=Dp)
-        return with_bf16_twin(dx.view(B, N, Dp), dxb), dw, db, None, None
+        acc = ln_grad_targets(ctx.ln, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        dx, dxb, dw, db = ops.layernorm_bwd(dy, Dp, x, Dp, w, mean, rstd, B * N, ctx.D, Dp, want_bf16=True, ld_dxb=Dp, acc=acc)
+        if acc is not None:
+            grad_done(ctx.ln.weight); grad_done(ctx.ln.bias)
+        return with_bf16_twin(dx.view(B, N, Dp), dxb), dw, db, None, None, None
 
 
 def layer_norm_padded(xp, ln: nn.LayerNorm):
-    return _LayerNormFn.apply(xp, ln.weight, ln.bias, ln.eps, ln.normalized_shape[0])
+    return _LayerNormFn.apply(xp, ln.weight, ln.bias, ln.eps, ln.normalized_shape[0], ln)
 
 
 class _LinearFn(torch.autograd.Function):

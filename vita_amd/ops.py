@@ -114,18 +114,27 @@ def layernorm_fwd(x, ldx, gamma, beta, rows, d, ldy, out_dtype=torch.bfloat16, e
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, lddy, x, ldx, gamma, mean, rstd, rows, d, lddx, dx_in=None, want_bf16=False, ld_dxb=0):
+def layernorm_bwd(dy, lddy, x, ldx, gamma, mean, rstd, rows, d, lddx, dx_in=None, want_bf16=False, ld_dxb=0, acc=None):
+    """acc = (dgamma_buf, dbeta_buf): fp32 [d] buffers the weight / bias gradients are ADDED to (None is then returned
+    for both) instead of being materialised."""
     dev = x.device
     dx = torch.empty(rows, lddx, dtype=torch.float32, device=dev)
     dxb = torch.empty(rows, ld_dxb, dtype=torch.bfloat16, device=dev) if want_bf16 else None
     nblk = _lib.lib().vita_layernorm_bwd_nblk(rows)
     partial = torch.empty(2 * nblk * d, dtype=torch.float32, device=dev)
-    dgamma = torch.empty(d, dtype=torch.float32, device=dev)
-    dbeta = torch.empty(d, dtype=torch.float32, device=dev)
-    check(_lib.lib().vita_layernorm_bwd(dy.data_ptr(), lddy, _dt(dy), x.data_ptr(), ldx, gamma.data_ptr(), mean.data_ptr(),
-                                        rstd.data_ptr(), _p(dx_in), dx.data_ptr(), lddx, _p(dxb), ld_dxb,
-                                        dgamma.data_ptr(), dbeta.data_ptr(), partial.data_ptr(), rows, d, _s()), "layernorm_bwd")
-    return dx, dxb, dgamma, dbeta
+    if acc is not None:
+        dgamma, dbeta = acc
+        assert dgamma.dtype == torch.float32 and dbeta.dtype == torch.float32 and dgamma.numel() == d and dbeta.numel() == d
+        assert dgamma.is_contiguous() and dbeta.is_contiguous()
+        fn = _lib.lib().vita_layernorm_bwd_acc
+    else:
+        dgamma = torch.empty(d, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(d, dtype=torch.float32, device=dev)
+        fn = _lib.lib().vita_layernorm_bwd
+    check(fn(dy.data_ptr(), lddy, _dt(dy), x.data_ptr(), ldx, gamma.data_ptr(), mean.data_ptr(),
+             rstd.data_ptr(), _p(dx_in), dx.data_ptr(), lddx, _p(dxb), ld_dxb,
+             dgamma.data_ptr(), dbeta.data_ptr(), partial.data_ptr(), rows, d, _s()), "layernorm_bwd")
+    return (dx, dxb, None, None) if acc is not None else (dx, dxb, dgamma, dbeta)
 
 
 def argsort_mask(noise: torch.Tensor, len_keep: int):
