@@ -284,14 +284,15 @@ def test_clip_pieces_and_mse(ops, golden):
     torch.testing.assert_close(loss.cpu()[0], O.reconstruction_mse(torch.sigmoid(zr.detach()), tgt, mask, True), rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("B,N,H,hd", [(2, 197, 5, 205), (1, 64, 3, 43), (2, 333, 2, 128), (1, 1000, 5, 205), (1, 31, 1, 32)])
+@pytest.mark.parametrize("B,N,H,hd", [(2, 197, 5, 205), (1, 64, 3, 43), (2, 333, 2, 128), (1, 1000, 5, 205), (1, 31, 1, 32),
+                                      (2, 1, 2, 205), (1, 33, 1, 43)])
 def test_flash_attention_fwd(ops, B, N, H, hd):
     torch.manual_seed(N)
     hdp = ops.rup(hd, 32)
     assert ops.attn_supported(hd, hdp)
     qkv = torch.zeros(B, N, 3, H, hdp)
     qkv[..., :hd] = torch.randn(B, N, 3, H, hd)
-    qkv[:, 3, 1, 0, :hd] *= 4.0     # one spiky key row: forces a late running-max jump (online-softmax rescale)
+    qkv[:, min(3, N - 1), 1, 0, :hd] *= 4.0     # one spiky key row: forces a late running-max jump (online-softmax rescale)
     qb = qkv.to(torch.bfloat16)
     q, k, v = [qb[:, :, i, :, :hd].float().permute(0, 2, 1, 3) for i in range(3)]
     scale = hd ** -0.5
@@ -309,7 +310,7 @@ def test_flash_attention_fwd(ops, B, N, H, hd):
 
 @pytest.mark.parametrize("handoff", [True, False], ids=["ds_handoff", "dq_recompute"])
 @pytest.mark.parametrize("B,N,H,hd", [(2, 197, 5, 205), (1, 64, 3, 43), (2, 333, 2, 128), (1, 700, 5, 205), (1, 31, 1, 32),
-                                      (1, 512, 2, 205), (2, 257, 1, 205), (1, 129, 3, 43)])
+                                      (1, 512, 2, 205), (2, 257, 1, 205), (1, 129, 3, 43), (2, 1, 2, 205), (1, 33, 1, 43)])
 def test_flash_attention_bwd(ops, B, N, H, hd, handoff):
     """Both dQ paths: dS tiles handed from the dK/dV kernel through the HBM scratch (default), and the dQ kernel that
     recomputes S / dP (ws == NULL).  Sizes cover N below one tile, N = k*256, and one row past a 128 / 256 boundary."""
@@ -335,6 +336,9 @@ def test_flash_attention_bwd(ops, B, N, H, hd, handoff):
     assert torch.isfinite(got).all() and not got[..., hd:].any()
     for i, name in enumerate("qkv"):
         g, r = got[:, :, i, :, :hd], leaf.grad[:, :, i, :, :hd]
+        if r.norm() == 0:        # N = 1: softmax over one key is constant, dQ = dK = 0 exactly
+            assert g.abs().max() < 1e-3, (name, g.abs().max())
+            continue
         err = ((g - r).norm() / r.norm()).item()
         assert err < 2e-2, (name, err)
 
