@@ -539,3 +539,28 @@ def test_gemm_large_m_epilogues(ops, lb):
     c3 = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
     ops.gemm(dev(A), wt, c3, m, n, k, k, ldb, n, epilogue=ops.EPI_GELU_BWD, aux_in=dev(uu), ld_aux=n, **kw)
     torch.testing.assert_close(c3.cpu().float(), pre_nb * uu.float(), rtol=2e-2, atol=2e-2)
+
+
+def test_empty_inputs_are_rejected_before_any_launch(ops):
+    """Empty batches / sequences never reach a kernel: every entry point validates sizes and pointers on the host and the
+    wrapper raises RuntimeError("... invalid argument ...").  (Stock torch would return empty tensors; the reference never
+    feeds an empty batch - its DataLoaders drop nothing and B >= 1 - so the drop-in fails loudly instead of guessing.)"""
+    d = "cuda"
+    bf = torch.bfloat16
+    from vita_amd.losses import CLIPLoss
+    cases = {
+        "layernorm rows=0": lambda: ops.layernorm_fwd(torch.zeros(0, 64, device=d), 64, torch.ones(33, device=d), torch.zeros(33, device=d), 0, 33, 64),
+        "gemm m=0": lambda: ops.gemm(torch.zeros(0, 64, device=d, dtype=bf), torch.zeros(64, 64, device=d, dtype=bf),
+                                     torch.zeros(0, 64, device=d, dtype=bf), 0, 64, 64, 64, 64, 64),
+        "argsort L=0": lambda: ops.argsort_mask(torch.zeros(2, 0, device=d), 0),
+        "argsort n=0": lambda: ops.argsort_mask(torch.zeros(0, 16, device=d), 4),
+        "cast rows=0": lambda: ops.cast_bf16(torch.zeros(0, 64, device=d), 64, 0, 33, 64),
+        "colsum rows=0": lambda: ops.colsum(torch.zeros(0, 64, device=d, dtype=bf), 64, 0, 64),
+        "attention N=0": lambda: ops.attn_fwd(torch.zeros(1, 0, 3, 1, 32, device=d, dtype=bf), torch.zeros(1, 0, 1, 32, device=d, dtype=bf),
+                                              torch.zeros(1, 1, 0, device=d), 1, 0, 1, 32, 32, 1.0),
+        "clip B=0": lambda: CLIPLoss(0.1)(torch.zeros(0, 128, device=d), torch.zeros(0, 128, device=d)),
+    }
+    for name, fn in cases.items():
+        with pytest.raises(RuntimeError, match="invalid argument"):
+            fn()
+    torch.cuda.synchronize()       # nothing was launched, nothing faulted
