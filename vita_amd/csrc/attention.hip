@@ -726,6 +726,17 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const uint16_t* __r
 #ifndef ATT_P_PRIO
 #define ATT_P_PRIO 3
 #endif
+#ifndef ATT_P_PRIO_PROD
+#define ATT_P_PRIO_PROD 0              // dP role: priority during its product (ATT_P_PRIO during its chain): the chain is the
+                                       // latency-bound phase; at equal priority in the products the older (S-role) wave's
+                                       // exp / pack work is not starved.  Decoder-layer backward 10.96 -> 10.82 ms (two same-box runs)
+#endif
+#ifndef ATT_S_PRIO_CHAIN
+#define ATT_S_PRIO_CHAIN 0             // S role: priority during its chain / its product
+#endif
+#ifndef ATT_S_PRIO_PROD
+#define ATT_S_PRIO_PROD 0
+#endif
 #define ATT_P_NQ 5
 #define ATT_P_NO 3
 template <int HDP> struct AttPLds {
@@ -885,10 +896,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_p_kernel(const uint16_t* __
       STAMP(0);
       f32x16 sacc;
       load_init(sacc, qrow, 0);
+      if (ATT_S_PRIO_CHAIN != ATT_S_PRIO_PROD) __builtin_amdgcn_s_setprio(ATT_S_PRIO_CHAIN);
       single_chain<HDP, NKS, 3>(sacc, smem, la, frag, [&](int s) {
 #pragma unroll
         for (int p = s; p <= 2 * NI; p += NKS) if (!(ATT_DBG & 256) || !(t & 1)) issue_piece(t + 3, qiss, t + 2, oiss, p);   // 256: timing only, half the Q / dO stream
       });
+      if (ATT_S_PRIO_CHAIN != ATT_S_PRIO_PROD) __builtin_amdgcn_s_setprio(ATT_S_PRIO_PROD);
       STAMP(1);
       uint32_t pwn[8];
       float pprev = 0.f;
@@ -932,10 +945,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_p_kernel(const uint16_t* __
       f32x16 dpacc;
       // row constants of tile t sit with Q tile t: slot (t + 1) % NQ = the slot after the transposed-read slot
       load_init(dpacc, qtr + 1 == NQ ? 0 : qtr + 1, 1);
+      if (ATT_P_PRIO_PROD != ATT_P_PRIO) __builtin_amdgcn_s_setprio(ATT_P_PRIO);
       single_chain<HDP, NKS, 3>(dpacc, smem, la, frag, [&](int s) {
 #pragma unroll
         for (int p = s; p <= 2 * NI; p += NKS) if (!(ATT_DBG & 256) || !(t & 1)) issue_piece(t + 3, qiss, t + 2, oiss, p);   // 256: timing only, half the Q / dO stream
       });
+      if (ATT_P_PRIO_PROD != ATT_P_PRIO) __builtin_amdgcn_s_setprio(ATT_P_PRIO_PROD);
       STAMP(1);
       const char* xp = smem + xlane + (t & 1) * 2048;
       const u32x4 pin0 = *reinterpret_cast<const u32x4*>(xp);
