@@ -115,6 +115,13 @@ __device__ __forceinline__ bf16x8 pack44(const f32x4& a, const f32x4& b) {
 #define ATT16_THR 8.0f      // see the lazy reference maximum in attn_fwd16_kernel
 #endif
 #define MFMA16(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)
+// The younger four waves of a workgroup (one per SIMD, beside an older one) run at this priority: at equal priority the older
+// wave of a SIMD wins every issue arbitration and the younger one is the critical path of every tile (phase stamps, DESIGN.md
+// section 4); N = 23 041 forward 3.67 -> 3.61 ms, N = 6 913 0.391 -> 0.383 ms (priority 1 and 3 alike).
+#ifndef ATT16_YOUNG_PRIO
+#define ATT16_YOUNG_PRIO 1
+#endif
+#define ATT16_NSLOT ATT_NSLOT
 
 // ============================================================================================ forward
 // ND = ceil(hd / 16): output column blocks that are computed; same arguments as attn_fwd_kernel.
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd16_kernel(const uint16_t* 
                                                                 float* __restrict__ lse, float* __restrict__ part, int wg_base,
                                                                 int nsplit, int tiles_per_split, int N, int H, float c_exp2) {
   using C = AttCfg<HDP>;
-  constexpr int RS = C::RS, NK = HDP / 32, BUF = 2 * C::TILE, NSLOT = ATT_NSLOT;
+  constexpr int RS = C::RS, NK = HDP / 32, BUF = 2 * C::TILE, NSLOT = ATT16_NSLOT;
   constexpr int NI = 32 / C::RPI / NW;                          // DMA pieces per wave per image
   constexpr int DPT = 2 * NI;                                   // DMA instructions per wave per tile
   constexpr int NA = 2 * NK;                                    // A fragments of the S chain (k-step x key block)
@@ -189,104 +196,114 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd16_kernel(const uint16_t* 
   unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = stamp_now();
   const unsigned long long st_begin = st_last;
 #endif
-  for (int kt = t0; kt < t1; ++kt) {
-    const int pre = slot >= 1 ? slot - 1 : NSLOT - 1;     // slot of tile kt+2 = slot of tile kt-1
+  bf16x8 pf0, pf1;           // P^T of the current tile, packed for the PV product (both query blocks)
+  // S chain of tile kt (K rows at la.rb) with the LDS-DMA pieces of tile `itile` -> ring slot `islot` issued between its
+  // MFMAs, then the softmax of the tile -> pf0 / pf1
+  auto s_phase = [&](int kt, int islot, int itile) __attribute__((always_inline)) {
     const int kbase = kt * 32;
-    STAMP(0);
-    if (active) {
-      f32x4 sacc[2][2];                                   // [key block][query block]
+    f32x4 sacc[2][2];                                   // [key block][query block]
 #pragma unroll
-      for (int i = 0; i < 4; ++i) sacc[i >> 1][i & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
-      {
-        // S chain: A fragment i = (k-step i >> 1, key block i & 1), read DEPTH fragments ahead; each feeds two MFMAs (both
-        // query blocks); the LDS-DMA pieces of tile kt+2 are issued between them
-        constexpr int DEPTH = 4;
-        bf16x8 a[DEPTH];
+    for (int i = 0; i < 4; ++i) sacc[i >> 1][i & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      // A fragment i = (k-step i >> 1, key block i & 1), read DEPTH fragments ahead; each feeds two MFMAs (both query blocks)
+      constexpr int DEPTH = 4;
+      bf16x8 a[DEPTH];
 #pragma unroll
-        for (int i = 0; i < DEPTH && i < NA; ++i) a[i] = la.row(smem, i >> 1, i & 1);
+      for (int i = 0; i < DEPTH && i < NA; ++i) a[i] = la.row(smem, i >> 1, i & 1);
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-          __builtin_amdgcn_sched_barrier(0);
-          sacc[i & 1][0] = MFMA16(a[i % DEPTH], qf[0][i >> 1], sacc[i & 1][0]);
-          sacc[i & 1][1] = MFMA16(a[i % DEPTH], qf[1][i >> 1], sacc[i & 1][1]);
-          if (i + DEPTH < NA) a[i % DEPTH] = la.row(smem, (i + DEPTH) >> 1, (i + DEPTH) & 1);
-#pragma unroll
-          for (int p = i; p < 2 * NI; p += NA) issue_piece(kt + 2, pre, p);
-        }
+      for (int i = 0; i < NA; ++i) {
         __builtin_amdgcn_sched_barrier(0);
+        sacc[i & 1][0] = MFMA16(a[i % DEPTH], qf[0][i >> 1], sacc[i & 1][0]);
+        sacc[i & 1][1] = MFMA16(a[i % DEPTH], qf[1][i >> 1], sacc[i & 1][1]);
+        if (i + DEPTH < NA) a[i % DEPTH] = la.row(smem, (i + DEPTH) >> 1, (i + DEPTH) & 1);
+#pragma unroll
+        for (int p = i; p < 2 * NI; p += NA) issue_piece(itile, islot, p);
       }
-      STAMP(1);
-      if (kbase + 32 > N) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (kbase + 16 * kb + 4 * g + j >= N) { sacc[kb][0][j] = -INFINITY; sacc[kb][1][j] = -INFINITY; }
-      }
-      // Lazy reference maximum: every lane takes the maximum of its own 8 scores per query; only when some lane of the wave
-      // sees a score more than ATT16_THR (in the exp2 domain) above its query's reference is the exact row maximum taken
-      // across the four lane groups and O / the row sums rescaled.  Probabilities are then bounded by 2^THR instead of 1,
-      // which changes nothing for bf16 / fp32 (a common power-of-two-like factor of a row cancels in O / l).
-      float lm[2];
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-        lm[qb] = fmaxf(fmaxf(fmaxf(sacc[0][qb][0], sacc[0][qb][1]), fmaxf(sacc[0][qb][2], sacc[0][qb][3])),
-                       fmaxf(fmaxf(sacc[1][qb][0], sacc[1][qb][1]), fmaxf(sacc[1][qb][2], sacc[1][qb][3])));
-      if (__any(lm[0] > m_thr[0] || lm[1] > m_thr[1])) {
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-          const float m_new = fmaxf(m_run[qb], xg_max(lm[qb]));
-          const float a = fast_exp2((m_run[qb] - m_new) * c_exp2);
-          lsum[qb] *= a;
-#pragma unroll
-          for (int i = 0; i < ND; ++i) oacc[i][qb] *= a;
-          m_run[qb] = m_new;
-          mc[qb] = m_new * c_exp2;
-          m_thr[qb] = m_new + thr_raw;
-        }
-      }
-      f32x4 p[2][2];
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) p[kb][qb][j] = fast_exp2(__builtin_fmaf(sacc[kb][qb][j], c_exp2, -mc[qb]));
-      const bf16x8 pf0 = pack44(p[0][0], p[1][0]), pf1 = pack44(p[0][1], p[1][1]);
-#if ATT_STAMP
-      asm volatile("" :: "v"(pf0), "v"(pf1));
-      STAMP(2);
-#endif
-      {
-        bf16x8 fr[3];      // transposed V fragments two column blocks ahead of their MFMAs
-        fr[0] = la.template tr_asm<0, C::TILE>();
-        if constexpr (ND > 1) fr[1] = la.template tr_asm<1, C::TILE>();
-        static_for<ND>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          if constexpr (i + 2 < ND) {
-            fr[(i + 2) % 3] = la.template tr_asm<i + 2, C::TILE>();
-            tr_wait<4>();
-          } else if constexpr (i + 1 < ND) {
-            tr_wait<2>();
-          } else {
-            tr_wait<0>();
-          }
-          oacc[i][0] = MFMA16(fr[i % 3], pf0, oacc[i][0]);
-          oacc[i][1] = MFMA16(fr[i % 3], pf1, oacc[i][1]);
-          if constexpr (i == 0) { lsum[0] = MFMA16(ones, pf0, lsum[0]); lsum[1] = MFMA16(ones, pf1, lsum[1]); }
-          __builtin_amdgcn_sched_barrier(0);
-        });
-      }
-      STAMP(3);
-    } else {
-      issue(kt + 2, pre);          // waves past the last query row only feed the ring
+      __builtin_amdgcn_sched_barrier(0);
     }
-    slot = slot + 1 == NSLOT ? 0 : slot + 1;
-    la.advance(slot == 0 ? -(NSLOT - 1) * BUF : BUF);
-    dma_wait_n<DPT>();             // tile kt+1 has landed
-    STAMP(4);
-    ring_barrier();
-    STAMP(5);
+    STAMP(1);
+    if (kbase + 32 > N) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (kbase + 16 * kb + 4 * g + j >= N) { sacc[kb][0][j] = -INFINITY; sacc[kb][1][j] = -INFINITY; }
+    }
+    // Lazy reference maximum: every lane takes the maximum of its own 8 scores per query; only when some lane of the wave
+    // sees a score more than ATT16_THR (in the exp2 domain) above its query's reference is the exact row maximum taken
+    // across the four lane groups and O / the row sums rescaled.  Probabilities are then bounded by 2^THR instead of 1,
+    // which changes nothing for bf16 / fp32 (a common power-of-two-like factor of a row cancels in O / l).
+    float lm[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+      lm[qb] = fmaxf(fmaxf(fmaxf(sacc[0][qb][0], sacc[0][qb][1]), fmaxf(sacc[0][qb][2], sacc[0][qb][3])),
+                     fmaxf(fmaxf(sacc[1][qb][0], sacc[1][qb][1]), fmaxf(sacc[1][qb][2], sacc[1][qb][3])));
+    if (__any(lm[0] > m_thr[0] || lm[1] > m_thr[1])) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const float m_new = fmaxf(m_run[qb], xg_max(lm[qb]));
+        const float a = fast_exp2((m_run[qb] - m_new) * c_exp2);
+        lsum[qb] *= a;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) oacc[i][qb] *= a;
+        m_run[qb] = m_new;
+        mc[qb] = m_new * c_exp2;
+        m_thr[qb] = m_new + thr_raw;
+      }
+    }
+    f32x4 p[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) p[kb][qb][j] = fast_exp2(__builtin_fmaf(sacc[kb][qb][j], c_exp2, -mc[qb]));
+    pf0 = pack44(p[0][0], p[1][0]); pf1 = pack44(p[0][1], p[1][1]);
+#if ATT_STAMP
+    asm volatile("" :: "v"(pf0), "v"(pf1));
+    STAMP(2);
+#endif
+  };
+  // O^T += V^T P^T of the tile whose V image la.tb addresses; row sums on the matrix pipe
+  auto pv_phase = [&]() __attribute__((always_inline)) {
+    bf16x8 fr[3];      // transposed V fragments two column blocks ahead of their MFMAs
+    fr[0] = la.template tr_asm<0, C::TILE>();
+    if constexpr (ND > 1) fr[1] = la.template tr_asm<1, C::TILE>();
+    static_for<ND>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (i + 2 < ND) {
+        fr[(i + 2) % 3] = la.template tr_asm<i + 2, C::TILE>();
+        tr_wait<4>();
+      } else if constexpr (i + 1 < ND) {
+        tr_wait<2>();
+      } else {
+        tr_wait<0>();
+      }
+      oacc[i][0] = MFMA16(fr[i % 3], pf0, oacc[i][0]);
+      oacc[i][1] = MFMA16(fr[i % 3], pf1, oacc[i][1]);
+      if constexpr (i == 0) { lsum[0] = MFMA16(ones, pf0, lsum[0]); lsum[1] = MFMA16(ones, pf1, lsum[1]); }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    STAMP(3);
+  };
+  if (ATT16_YOUNG_PRIO && wave >= NW / 2) __builtin_amdgcn_s_setprio(ATT16_YOUNG_PRIO);
+  {
+    for (int kt = t0; kt < t1; ++kt) {
+      int pre = slot + 2; if (pre >= NSLOT) pre -= NSLOT;     // slot of tile kt+2
+      STAMP(0);
+      if (active) {
+        s_phase(kt, pre, kt + 2);
+        pv_phase();
+      } else {
+        issue(kt + 2, pre);          // waves past the last query row only feed the ring
+      }
+      slot = slot + 1 == NSLOT ? 0 : slot + 1;
+      la.advance(slot == 0 ? -(NSLOT - 1) * BUF : BUF);
+      dma_wait_n<DPT>();             // tile kt+1 has landed
+      STAMP(4);
+      ring_barrier();
+      STAMP(5);
+    }
   }
 #if ATT_STAMP
   if (lane == 0 && nsplit == 1 && blockIdx.x < ATT_STAMP_WG) {
@@ -343,7 +360,7 @@ template <int HDP, int ND>
 static int launch_fwd16(const void* qkv, void* o, float* lse, void* ws, int64_t B, int64_t N, int64_t H, float scale, hipStream_t s) {
   constexpr int NW = 8;
   static const bool no_tail = att_env_flag("VITA_ATTN_NO_TAIL_SPLIT");
-  const size_t lds = ATT_NSLOT * 2 * AttCfg<HDP>::TILE;
+  const size_t lds = ATT16_NSLOT * 2 * AttCfg<HDP>::TILE;
   const void* fn = (const void*)attn_fwd16_kernel<HDP, ND, NW>;
   VITA_ONCE_PER_DEVICE((void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   auto kern = attn_fwd16_kernel<HDP, ND, NW>;
