@@ -197,3 +197,10 @@ def test_bench_traffic_lookup_knows_the_profiled_kernels():
     assert traffic is not None and src == os.path.basename(t50[0])
     # Q, K, V, O, dO in and dQ, dK, dV out of the smaller (encoder) launch: B=2, N=6913, H=5, hdp=224, bf16
     assert traffic > 8 * 2 * 6913 * 5 * 224 * 2
+
+
+def test_product_library_is_not_a_diagnostic_build():
+    """Timing-only dissection switches (ATT_DBG, G2_DBG) and phase stamps (ATT_STAMP) compile marker symbols in; the library
+    the product loads must carry none (vita_amd/_lib.py warns about a library that does)."""
+    lib = ctypes.CDLL(os.path.join(ROOT, "vita_amd", "libvita_hip.so"))
+    assert not hasattr(lib, "vita_debug_build_attn") and not hasattr(lib, "vita_debug_build_gemm")

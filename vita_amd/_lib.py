@@ -104,6 +104,15 @@ def lib():
         fn.restype = i64 if name in _I64_RET else C.c_int
     l.vita_last_error.restype = C.c_char_p
     l.vita_last_error.argtypes = []
+    # Diagnostic builds (timing-only dissection switches ATT_DBG / G2_DBG, phase stamps ATT_STAMP) export these markers: such a
+    # library computes WRONG results by design (or carries stamp overhead) and must never be mistaken for the product build
+    for marker in ("vita_debug_build_attn", "vita_debug_build_gemm"):
+        if hasattr(l, marker):
+            flags = int(getattr(l, marker)())
+            if flags:
+                import warnings
+                warnings.warn(f"vita_amd: {LIB_PATH} is a DIAGNOSTIC build ({marker} = {flags}): timing only, results may be INVALID",
+                              RuntimeWarning, stacklevel=2)
     _lib = l
     return l
 

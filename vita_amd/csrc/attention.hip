@@ -1487,6 +1487,10 @@ static int launch_bwd(const void* qkv, const void* o, const void* dout, const fl
   if (hdp == 32 && nks == 2) return CALL(32, 2);             \
   if (hdp == 128 && nks == 8) return CALL(128, 8);
 
+#if ATT_DBG || ATT_STAMP
+// marker of a diagnostic build (vita_amd/_lib.py warns when it finds it): timing-only switches / phase stamps are compiled in
+extern "C" int vita_debug_build_attn(void) { return ATT_DBG | (ATT_STAMP << 16); }
+#endif
 extern "C" int vita_attn_supported(int64_t hd, int64_t hdp) {
   const int64_t nks = (hd + 15) / 16;
   return (hdp == 224 && nks == 13) || (hdp == 64 && nks == 3) || (hdp == 32 && nks == 2) || (hdp == 128 && nks == 8);

@@ -598,6 +598,10 @@ double vita_gemm128_cost(const vita_gemm_desc& d) {
   const int64_t t = ((d.m + 127) / 128) * ((d.n + 127) / 128) * d.split_k;
   return (double)((t + 255) / 256) * 8.75 / d.split_k;
 }
+#if G2_DBG
+// marker of a timing-only build (vita_amd/_lib.py warns when it finds it)
+extern "C" int vita_debug_build_gemm(void) { return G2_DBG; }
+#endif
 // Whether the large-tile kernel can run this descriptor (already validated / normalised by vita_gemm_bf16).
 bool vita_gemm256_supported(const vita_gemm_desc& d) {
   if (d.batch_outer * d.batch_inner != 1) return false;
