@@ -225,6 +225,49 @@ def test_block_reference_dims(N, use_flash):
         assert rel(v.grad, leaves[k].grad) < 2e-2, k
 
 
+@pytest.mark.parametrize("D,H,B,N,ratio,qkv_bias", [
+    (96, 3, 1, 1, 4.0, True),        # a single token
+    (129, 3, 3, 33, 4.0, True),      # cfg1 width, one row past a 32-token tile
+    (160, 5, 2, 257, 2.0, False),    # head dim 32 exactly, no qkv bias, mlp_ratio 2
+    (205, 1, 1, 130, 4.0, True),     # one head of the reference's 205
+    (512, 4, 2, 64, 1.0, True),      # head dim 128, hidden = D
+    (344, 8, 1, 500, 3.0, True),     # head dim 43 -> padded 64
+    (1025, 5, 1, 129, 4.0, True),    # reference dims, one row past a 128-key block
+    (260, 2, 2, 96, 4.0, True),      # head dim 130: no fused kernel -> materialised attention path
+])
+def test_block_assorted_configs(D, H, B, N, ratio, qkv_bias):
+    """Block forward + every gradient against the oracle over widths / head sizes / sequence lengths / mlp ratios the
+    reference's three call sites could be constructed with (imaging encoder, decoder, TabularViT), including shapes with no
+    fused attention kernel (falls back to the materialised path) and degenerate sequence lengths."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from vita_amd.nn import Block
+    hidden = int(D * ratio)
+    p = {}
+    O.init_block(p, "", D, hidden, torch.Generator().manual_seed(D + N))
+    g = torch.Generator().manual_seed(N)
+    for k in list(p):
+        if k.endswith("bias"):
+            p[k] = torch.randn(p[k].shape, generator=g) * 0.05
+    if not qkv_bias:
+        p["attn.qkv.bias"] = torch.zeros(3 * D)           # the oracle's Linear always takes a bias: zero = none
+    blk = Block(D, H, ratio, qkv_bias=qkv_bias).cuda()
+    blk.load_state_dict({k: v for k, v in p.items() if qkv_bias or k != "attn.qkv.bias"}, strict=True)
+    x = torch.randn(B, N, D, generator=g)
+    cot = torch.randn(B, N, D, generator=g)
+    xg = x.cuda().requires_grad_(True)
+    y = blk(xg)
+    (y * cot.cuda()).sum().backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = O.block_forward(xr, leaves, "", H)
+    (yr * cot).sum().backward()
+    assert rel(y, yr) < 2e-2
+    assert rel(xg.grad, xr.grad) < 2e-2
+    for k, v in blk.named_parameters():
+        assert rel(v.grad, leaves[k].grad) < 2e-2, k
+
+
 def test_side_stream_runs_beside_the_main_stream():
     """The second stream of the Block backward is chosen by a concurrency probe (vita_amd.nn._concurrent_stream): HIP
     streams that share a hardware queue serialise.  Even after many other streams were taken from the pool, two 0.5 ms
