@@ -75,6 +75,37 @@ def test_encoder_forward_and_indices():
     assert m2 is None and i2 is None and rel(x2, yr) < 2e-2
 
 
+@pytest.mark.parametrize("img,ratio", [((9, 5, 16, 16), 0.5), ((9, 10, 32, 32), 0.9), ((9, 5, 32, 16), 0.25), ((9, 10, 16, 16), 0.0),
+                                       ((9, 10, 32, 32), 0.99)])
+def test_encoder_assorted_mask_ratios_and_grids(img, ratio):
+    """Mask ratios from 0 (no masking: mask / ids are None) to 0.99 (len_keep = int(L * 0.01), as the reference truncates),
+    a non-square H x W grid and several T: mask and ids_restore bit-exact, kept tokens within the bf16 tolerance."""
+    cfg = dict(CFG, mask_ratio=ratio)
+    model, p = build(cfg, img)
+    L = 9 * (img[1] // 5) * (img[2] // 8) * (img[3] // 8)
+    torch.manual_seed(3)
+    imgs = torch.rand(2, *img)
+    noise = draw_noise(77, 2, L)
+    x, mask, ids = model.encoder_imaging(imgs.cuda())
+    xr, mr, ir = O.encoder_forward(imgs, p, patch_size=CFG["patch_size"], num_heads=3, depth=2, mask_ratio=ratio,
+                                   noise=noise if ratio > 0 else None, prefix="encoder_imaging.")
+    assert x.shape == xr.shape == (2, 1 + int(L * (1 - ratio)), 129)
+    if ratio > 0:
+        assert torch.equal(mask.cpu(), mr) and torch.equal(ids.cpu(), ir)
+        assert int(mask.sum().item()) == 2 * (L - int(L * (1 - ratio)))
+    else:
+        assert mask is None and ids is None and mr is None and ir is None
+    assert rel(x, xr) < 2e-2
+
+
+def test_encoder_rejects_a_mask_that_keeps_no_token():
+    """len_keep = int(L * (1 - mask_ratio)) = 0 (36 tokens at ratio 0.99): the reference would run its blocks on the cls token
+    alone; no shipped configuration comes near it, and the drop-in refuses it loudly instead of carrying an empty-GEMM path."""
+    model, _ = build(dict(CFG, mask_ratio=0.99), (9, 5, 16, 16))
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        model.encoder_imaging(torch.rand(2, 9, 5, 16, 16).cuda())
+
+
 def test_patch_embed_golden(golden):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
