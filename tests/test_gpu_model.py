@@ -367,6 +367,29 @@ def test_block_backward_side_stream_matches_single_stream():
     assert vnn._DEFERRED_DONE is None
 
 
+@pytest.mark.parametrize("B,d,lam,tau", [(1, 128, 0.5, 0.1), (2, 128, 0.3, 0.1), (3, 7, 0.0, 0.07), (33, 128, 1.0, 0.5), (257, 64, 0.5, 0.1)])
+def test_clip_loss_assorted_batches(B, d, lam, tau):
+    """CLIPLoss at batch sizes the fixtures do not hold - a single pair (loss 0, zero gradients), odd sizes, one past a
+    256 boundary - and at lambda_0 = 0 / 1 (one of the two cross-entropies switched off), against the restatement that
+    g5 pins (fp32: 1e-4)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from vita_amd.losses import CLIPLoss
+    g = torch.Generator().manual_seed(B * 1000 + d)
+    a = torch.randn(B, d, generator=g); b = torch.randn(B, d, generator=g)
+    ar = a.clone().requires_grad_(True); br = b.clone().requires_grad_(True)
+    lr, logr, labr = O.clip_loss(ar, br, tau, lam)
+    lr.backward()
+    ag = a.cuda().requires_grad_(True); bg = b.cuda().requires_grad_(True)
+    l, logits, labels = CLIPLoss(tau, lam)(ag, bg)
+    l.backward()
+    torch.testing.assert_close(l.cpu(), lr.detach(), rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(logits.cpu(), logr.detach(), rtol=1e-4, atol=1e-5)
+    assert torch.equal(labels.cpu(), labr)
+    torch.testing.assert_close(ag.grad.cpu(), ar.grad, rtol=1e-3, atol=1e-6)
+    torch.testing.assert_close(bg.grad.cpu(), br.grad, rtol=1e-3, atol=1e-6)
+
+
 def test_clip_loss_golden(golden):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
